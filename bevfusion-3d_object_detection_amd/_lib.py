@@ -1,0 +1,77 @@
+"""ctypes binding of csrc/libbevfusion_hip.so (the C ABI declared in include/bevfusion_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised (the reference raises RuntimeError from its C++ exceptions as well,
+BF/ops/voxel/src/voxelization.h:75).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbevfusion_hip.so")
+
+_c_int = ctypes.c_int
+_c_vp = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/bevfusion_hip.h
+SIGNATURES = {
+    "bfhip_abi_version": (_c_int, []),
+    "bfhip_last_error": (ctypes.c_char_p, []),
+    "bfhip_bev_pool_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 7 + [_c_vp, _c_vp]),
+    "bfhip_bev_pool_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 8 + [_c_vp, _c_vp]),
+    "bfhip_dynamic_voxelize": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
+    "bfhip_hard_voxelize_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "bfhip_hard_voxelize": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
+                                     _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; raise loudly if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libbevfusion_hip.so not found at %s: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().bfhip_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def host_f32(values):
+    arr = (ctypes.c_float * len(values))(*[float(v) for v in values])
+    return arr
+
+
+def require_cuda(t, name):
+    # mirrors CHECK_INPUT (BF/ops/voxel/src/voxelization_cuda.cu:8-14): device + contiguous
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA(HIP) tensor; this build has no CPU path" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)

@@ -1,0 +1,55 @@
+// common.h -- shared helpers of libbevfusion_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/bevfusion_hip.h"
+
+#define BFHIP_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace bfhip {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return BFHIP_E_LAUNCH;
+  }
+  return BFHIP_OK;
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller-provided workspace
+struct Workspace {
+  char *base;
+  size_t size, off;
+  Workspace(void *p, size_t n) : base((char *)p), size(n), off(0) {}
+  template <typename T>
+  T *take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T), 256);
+    if (off + bytes > size) { off = size + 1; return nullptr; }
+    T *r = (T *)(base + off);
+    off += bytes;
+    return r;
+  }
+  bool ok() const { return off <= size; }
+};
+
+}  // namespace bfhip
+
+#define BFHIP_REQUIRE(cond, ...)                \
+  do {                                          \
+    if (!(cond)) {                              \
+      bfhip::set_error(__VA_ARGS__);            \
+      return BFHIP_E_INVALID;                   \
+    }                                           \
+  } while (0)

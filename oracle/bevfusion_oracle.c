@@ -1,0 +1,482 @@
+/*
+ * bevfusion_oracle.c -- CPU restatement of the reference's hot-path algorithms.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load this library.  The product (the HIP extension under
+ * bevfusion-3d_object_detection_amd/csrc) never links, imports or falls back to it.
+ *
+ * Every function cites the reference lines it restates (paths relative to /root/reference,
+ * BF/ = projects/BEVFusion/bevfusion/).  Single-threaded, plain C99, compiled with
+ * -ffp-contract=off so that no FMA is formed (the reference's CPU build does not form them
+ * either at -O2 on x86-64 without -march flags).
+ *
+ * Pinning (see tests/test_oracle_golden.py, tests/golden/):
+ *   - dynamic/hard voxelization: checked against the reference's compiled CPU extension
+ *     (oracle/_ref, built by oracle/build_ref.sh from the sources in place) and against the
+ *     reference's only known-answer test (tests/test_models/test_task_modules/test_voxel/
+ *     test_voxel_generator.py:7-20).
+ *   - bev_pool: the reference has NO CPU implementation and no test; the restatement follows
+ *     the CUDA kernel line by line and is cross-checked against two independent formulations
+ *     (fp64 QuickCumsum restated from BF/ops/bev_pool/bev_pool.py:7-34, and index_add).
+ *   - dynamic scatter: no CPU binding in the reference ("do not support cpu yet",
+ *     BF/ops/voxel/src/voxelization.h:118,139) and no test -> parity unpinned by fixtures;
+ *     restated from the CUDA wrapper + torch.unique_dim semantics.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * grid size: BF/ops/voxel/src/voxelization_cpu.cpp:121-124 (same at voxelization_cuda.cu:256-258)
+ *   grid_size[i] = round((coors_range[NDim + i] - coors_range[i]) / voxel_size[i]);   (float math)
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API void oracle_grid_size(const float *voxel_size, const float *coors_range, int ndim,
+                                 int *grid_size) {
+  for (int i = 0; i < ndim; ++i) {
+    float q = (coors_range[ndim + i] - coors_range[i]) / voxel_size[i];
+    grid_size[i] = (int)round((double)q);
+  }
+}
+
+/* One coordinate.  BF/ops/voxel/src/voxelization_cpu.cpp:24-29:
+ *   c = floor((points[i][j] - coors_range[j]) / voxel_size[j]);  if (c < 0 || c >= grid) failed
+ * fp32 subtract, fp32 divide, floor, int conversion.  The reference converts an out-of-int-range
+ * or NaN float to int (UB; x86 cvttss2si yields INT_MIN => "failed").  We define that case as
+ * failed explicitly. */
+static inline int voxel_coord(float p, float lo, float vs, int grid, int *c_out) {
+  float f = floorf((p - lo) / vs);
+  if (!(f >= 0.0f && f < (float)grid)) return 0;
+  *c_out = (int)f;
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dynamic_voxelize_cpu: BF/ops/voxel/src/voxelization_cpu.cpp:8-43 (kernel) and :146-171 (wrapper).
+ * coors[i] = (cx,cy,cz) or (-1,-1,-1) if ANY axis fails (CPU semantics, :34-39).
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API void oracle_dynamic_voxelize(const float *points, int num_points, int num_features,
+                                        const float *voxel_size, const float *coors_range,
+                                        int ndim, int32_t *coors) {
+  int grid[3];
+  oracle_grid_size(voxel_size, coors_range, ndim, grid);
+  for (int i = 0; i < num_points; ++i) {
+    int c[3] = {0, 0, 0};
+    int failed = 0;
+    for (int j = 0; j < ndim; ++j) {
+      if (!voxel_coord(points[(size_t)i * num_features + j], coors_range[j], voxel_size[j], grid[j],
+                       &c[j])) {
+        failed = 1;
+        break;
+      }
+    }
+    for (int k = 0; k < ndim; ++k) coors[(size_t)i * ndim + k] = failed ? -1 : c[k];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * hard_voxelize_cpu: BF/ops/voxel/src/voxelization_cpu.cpp:46-101 (kernel), :107-144 (wrapper).
+ * First-come grouping.  The reference allocates coor_to_voxelidx as [gz,gy,gx] but indexes it
+ * [x][y][z] (:75,83 vs :129-130) which is out of bounds on non-cubic grids (segfaults at the
+ * nuScenes grid).  The restatement uses a correctly indexed dense table [gx][gy][gz], freshly
+ * allocated and filled with -1 per call exactly as the reference does (:129-130), so the CPU
+ * baseline pays the same table cost.
+ * voxels/coors/num_points_per_voxel are caller-allocated and caller-zeroed (BF/ops/voxel/voxelize.py:51-53).
+ * returns voxel_num.
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API int oracle_hard_voxelize(const float *points, int num_points, int num_features,
+                                    const float *voxel_size, const float *coors_range,
+                                    int max_points, int max_voxels, float *voxels, int32_t *coors,
+                                    int32_t *num_points_per_voxel) {
+  const int ndim = 3;
+  int grid[3];
+  oracle_grid_size(voxel_size, coors_range, ndim, grid);
+  size_t cells = (size_t)grid[0] * grid[1] * grid[2];
+  int32_t *table = (int32_t *)malloc(cells * sizeof(int32_t));
+  if (!table) return -1;
+  memset(table, 0xff, cells * sizeof(int32_t)); /* -1 */
+  int32_t *temp = (int32_t *)malloc((size_t)num_points * 3 * sizeof(int32_t));
+  if (!temp) { free(table); return -1; }
+  oracle_dynamic_voxelize(points, num_points, num_features, voxel_size, coors_range, ndim, temp);
+
+  int voxel_num = 0;
+  for (int i = 0; i < num_points; ++i) {
+    const int32_t *c = temp + (size_t)i * 3;
+    if (c[0] == -1) continue;                                   /* :73 */
+    size_t cell = ((size_t)c[0] * grid[1] + c[1]) * grid[2] + c[2];
+    int voxelidx = table[cell];                                 /* :75 */
+    if (voxelidx == -1) {                                       /* :78 */
+      voxelidx = voxel_num;
+      if (max_voxels != -1 && voxel_num >= max_voxels) continue; /* :80 */
+      voxel_num += 1;
+      table[cell] = voxelidx;                                   /* :83 */
+      for (int k = 0; k < ndim; ++k) coors[(size_t)voxelidx * 3 + k] = c[k]; /* :85-87 */
+    }
+    int num = num_points_per_voxel[voxelidx];                   /* :91 */
+    if (max_points == -1 || num < max_points) {                 /* :92 */
+      float *dst = voxels + ((size_t)voxelidx * max_points + num) * num_features;
+      memcpy(dst, points + (size_t)i * num_features, sizeof(float) * num_features);
+      num_points_per_voxel[voxelidx] += 1;
+    }
+  }
+  free(temp);
+  free(table);
+  return voxel_num;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Mean reduce of hard voxels: BF/bevfusion.py:251-253
+ *   feats = feats.sum(dim=1) / sizes.type_as(feats).view(-1,1)
+ * torch.sum over dim=1 of a [M,P,F] fp32 tensor: P=10 strided elements per output.  ATen's CPU
+ * reduction for this shape accumulates sequentially over the reduced dim in fp32 (vectorised
+ * across the F/outer dim, not across P).  Restated as a sequential fp32 sum; tests allow 1e-6 rel
+ * against torch to absorb a different association.
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API void oracle_voxel_mean(const float *voxels, const int32_t *num_points, int M, int P,
+                                  int F, float *feats) {
+  for (int v = 0; v < M; ++v) {
+    for (int f = 0; f < F; ++f) {
+      float s = 0.f;
+      for (int p = 0; p < P; ++p) s += voxels[((size_t)v * P + p) * F + f];
+      feats[(size_t)v * F + f] = s / (float)num_points[v];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Interval construction: BF/ops/bev_pool/bev_pool.py:48-54 (QuickCumsumTrainingCuda.forward)
+ *   kept[0]=1; kept[i]= ranks[i]!=ranks[i-1]; starts = where(kept); lengths = diff, last = n-start
+ * returns n_intervals.
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API int oracle_intervals_from_ranks(const int64_t *ranks, int n, int32_t *starts,
+                                           int32_t *lengths) {
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (i == 0 || ranks[i] != ranks[i - 1]) starts[m++] = i;
+  }
+  for (int k = 0; k < m; ++k) lengths[k] = (k + 1 < m ? starts[k + 1] : n) - starts[k];
+  return m;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * bev_pool forward: BF/ops/bev_pool/src/bev_pool_cuda.cu:20-42; out zero-initialised by the
+ * wrapper BF/ops/bev_pool/src/bev_pool.cpp:38-40.  geom row layout [x, y, z, b] (:34-36),
+ * out layout [b, d(z), h(x), w(y), c].  psum is a sequential fp32 sum in row order (:38-40),
+ * and the cell is OVERWRITTEN (:41).
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API void oracle_bev_pool_fwd(const float *x, const int32_t *geom, const int32_t *starts,
+                                    const int32_t *lengths, int n, int c, int m, int b, int d,
+                                    int h, int w, float *out) {
+  (void)n;
+  memset(out, 0, sizeof(float) * (size_t)b * d * h * w * c);
+  for (int k = 0; k < m; ++k) {
+    int s = starts[k], len = lengths[k];
+    const int32_t *g = geom + (size_t)s * 4;
+    float *o = out + ((((size_t)g[3] * d + g[2]) * h + g[0]) * w + g[1]) * c;
+    for (int ch = 0; ch < c; ++ch) {
+      float psum = 0.f;
+      for (int i = 0; i < len; ++i) psum += x[((size_t)s + i) * c + ch];
+      o[ch] = psum;
+    }
+  }
+}
+
+/* bev_pool backward: BF/ops/bev_pool/src/bev_pool_cuda.cu:61-84; x_grad zero-initialised by
+ * BF/ops/bev_pool/src/bev_pool.cpp:76-78; every row of the interval receives out_grad[cell]. */
+ORACLE_API void oracle_bev_pool_bwd(const float *out_grad, const int32_t *geom,
+                                    const int32_t *starts, const int32_t *lengths, int n, int c,
+                                    int m, int b, int d, int h, int w, float *x_grad) {
+  (void)b;
+  memset(x_grad, 0, sizeof(float) * (size_t)n * c);
+  for (int k = 0; k < m; ++k) {
+    int s = starts[k], len = lengths[k];
+    const int32_t *g = geom + (size_t)s * 4;
+    const float *o = out_grad + ((((size_t)g[3] * d + g[2]) * h + g[0]) * w + g[1]) * c;
+    for (int i = 0; i < len; ++i) memcpy(x_grad + ((size_t)s + i) * c, o, sizeof(float) * c);
+  }
+}
+
+/* Independent formulation #2 (double precision): QuickCumsum, BF/ops/bev_pool/bev_pool.py:7-34
+ *   x.cumsum(0); keep last row of each rank; first-difference.  Evaluated in fp64 (in fp32 the
+ *   prefix-sum cancellation error exceeds the 1e-3 budget).  out_cells[m][c] in interval order. */
+ORACLE_API void oracle_quickcumsum_f64(const float *x, const int64_t *ranks, int n, int c,
+                                       double *out_cells) {
+  double *cum = (double *)calloc((size_t)c, sizeof(double));
+  double *prev = (double *)calloc((size_t)c, sizeof(double));
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    for (int ch = 0; ch < c; ++ch) cum[ch] += (double)x[(size_t)i * c + ch];
+    if (i == n - 1 || ranks[i + 1] != ranks[i]) {
+      for (int ch = 0; ch < c; ++ch) {
+        out_cells[(size_t)m * c + ch] = cum[ch] - prev[ch];
+        prev[ch] = cum[ch];
+      }
+      ++m;
+    }
+  }
+  free(cum);
+  free(prev);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Fused lift-splat (view-transform boundary).  Restates, without materialising x[N',C]:
+ *   BF/depth_lss.py:723-725   x = depth.unsqueeze(1) * feat.unsqueeze(2)  -> [BN, C, D, fH, fW]
+ *                             permuted to [B, N, D, fH, fW, C] and flattened to rows
+ *   BF/depth_lss.py:190-194   x = x[kept][indices]
+ *   BF/ops/bev_pool/src/bev_pool_cuda.cu:20-42  interval sum
+ * depth  f32[BN, D, fH, fW]   (softmax output)
+ * feat   f32[BN, C, fH, fW]   (channel-major, as produced by depthnet, depth_lss.py:699-701)
+ * src    i32[nk]  flat frustum row index (bn*D*fH*fW + d*fH*fW + hw) of the k-th sorted kept point
+ * product is rounded to fp32 before the sum exactly like the materialised tensor would be.
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API void oracle_lift_splat_fwd(const float *depth, const float *feat, const int32_t *src,
+                                      const int32_t *geom, const int32_t *starts,
+                                      const int32_t *lengths, int nk, int m, int BN, int D, int HW,
+                                      int C, int b, int d, int h, int w, float *out) {
+  (void)nk; (void)BN;
+  memset(out, 0, sizeof(float) * (size_t)b * d * h * w * C);
+  for (int k = 0; k < m; ++k) {
+    int s = starts[k], len = lengths[k];
+    const int32_t *g = geom + (size_t)s * 4;
+    float *o = out + ((((size_t)g[3] * d + g[2]) * h + g[0]) * w + g[1]) * C;
+    for (int ch = 0; ch < C; ++ch) {
+      float psum = 0.f;
+      for (int i = 0; i < len; ++i) {
+        int r = src[s + i];
+        int bn = r / (D * HW), rem = r % (D * HW);
+        int hw = rem % HW;
+        float dep = depth[r];
+        float f = feat[((size_t)bn * C + ch) * HW + hw];
+        float prod = dep * f;
+        psum += prod;
+      }
+      o[ch] = psum;
+    }
+  }
+}
+
+/* Backward of the fused op (autograd of the three restated steps above):
+ *   d_x[row] = out_grad[cell(row)]                     (bev_pool_cuda.cu:61-84)
+ *   d_depth[r] = sum_c d_x[row(r)][c] * feat[bn,c,hw]  (product rule on depth_lss.py:723)
+ *   d_feat[bn,c,hw] = sum_d d_x[row(bn,d,hw)][c] * depth[bn,d,hw]
+ * rows not kept get zero gradient.  Accumulation order: d_depth sums channels ascending;
+ * d_feat sums sorted positions ascending (both fp32). */
+ORACLE_API void oracle_lift_splat_bwd(const float *out_grad, const float *depth, const float *feat,
+                                      const int32_t *src, const int32_t *geom,
+                                      const int32_t *starts, const int32_t *lengths, int nk, int m,
+                                      int BN, int D, int HW, int C, int b, int d, int h, int w,
+                                      float *d_depth, float *d_feat) {
+  (void)nk; (void)b;
+  memset(d_depth, 0, sizeof(float) * (size_t)BN * D * HW);
+  memset(d_feat, 0, sizeof(float) * (size_t)BN * C * HW);
+  for (int k = 0; k < m; ++k) {
+    int s = starts[k], len = lengths[k];
+    const int32_t *g = geom + (size_t)s * 4;
+    const float *o = out_grad + ((((size_t)g[3] * d + g[2]) * h + g[0]) * w + g[1]) * C;
+    for (int i = 0; i < len; ++i) {
+      int r = src[s + i];
+      int bn = r / (D * HW), rem = r % (D * HW);
+      int hw = rem % HW;
+      float dep = depth[r];
+      float acc = 0.f;
+      for (int ch = 0; ch < C; ++ch) {
+        float f = feat[((size_t)bn * C + ch) * HW + hw];
+        acc += o[ch] * f;
+        d_feat[((size_t)bn * C + ch) * HW + hw] += o[ch] * dep;
+      }
+      d_depth[r] = acc;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Dynamic scatter forward: BF/ops/voxel/src/scatter_points_cuda.cu:183-239
+ *   coors_clean: rows with any negative coord -> (-1,-1,-1)            (:202)
+ *   unique_dim(coors_clean, 0, sorted=True, inverse, counts)            (:204-205) lexicographic
+ *   drop the leading (-1,-1,-1) group, coors_map -= 1                    (:207-212)
+ *   reduce max (init -inf) / sum / mean (sum then divide)               (:220-234)
+ * returns M (number of voxels).  out buffers sized for N rows.
+ * reduce_type: 0 SUM, 1 MEAN, 2 MAX (enum at scatter_points_cuda.cu:7).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int32_t c[3]; int32_t idx; } coor_rec_t;
+static int coor_cmp(const void *a, const void *b) {
+  const coor_rec_t *x = (const coor_rec_t *)a, *y = (const coor_rec_t *)b;
+  for (int k = 0; k < 3; ++k) {
+    if (x->c[k] != y->c[k]) return x->c[k] < y->c[k] ? -1 : 1;
+  }
+  return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+ORACLE_API int oracle_dynamic_scatter_fwd(const float *feats, const int32_t *coors, int N, int C,
+                                          int reduce_type, float *voxel_feats,
+                                          int32_t *voxel_coors, int32_t *point2voxel,
+                                          int32_t *voxel_count) {
+  if (N == 0) return 0;
+  coor_rec_t *rec = (coor_rec_t *)malloc(sizeof(coor_rec_t) * (size_t)N);
+  for (int i = 0; i < N; ++i) {
+    const int32_t *c = coors + (size_t)i * 3;
+    int neg = (c[0] < 0) || (c[1] < 0) || (c[2] < 0);
+    for (int k = 0; k < 3; ++k) rec[i].c[k] = neg ? -1 : c[k];
+    rec[i].idx = i;
+  }
+  qsort(rec, (size_t)N, sizeof(coor_rec_t), coor_cmp);
+  int M = 0;
+  int has_neg = rec[0].c[0] < 0;
+  int group = -1;
+  for (int i = 0; i < N; ++i) {
+    if (i == 0 || memcmp(rec[i].c, rec[i - 1].c, sizeof(int32_t) * 3) != 0) ++group;
+    int vid = group - (has_neg ? 1 : 0);
+    point2voxel[rec[i].idx] = vid;
+    if (vid >= 0) {
+      if (vid == M) {
+        memcpy(voxel_coors + (size_t)vid * 3, rec[i].c, sizeof(int32_t) * 3);
+        voxel_count[vid] = 0;
+        ++M;
+      }
+      voxel_count[vid] += 1;
+    }
+  }
+  free(rec);
+  for (size_t j = 0; j < (size_t)M * C; ++j) voxel_feats[j] = (reduce_type == 2) ? -INFINITY : 0.f;
+  /* atomics in the reference: order unspecified; point-index order used here */
+  for (int i = 0; i < N; ++i) {
+    int v = point2voxel[i];
+    if (v < 0) continue;
+    for (int ch = 0; ch < C; ++ch) {
+      float f = feats[(size_t)i * C + ch];
+      float *o = voxel_feats + (size_t)v * C + ch;
+      if (reduce_type == 2) *o = fmaxf(*o, f); else *o += f;
+    }
+  }
+  if (reduce_type == 1) {
+    for (int v = 0; v < M; ++v)
+      for (int ch = 0; ch < C; ++ch) voxel_feats[(size_t)v * C + ch] /= (float)voxel_count[v];
+  }
+  return M;
+}
+
+/* Dynamic scatter backward: BF/ops/voxel/src/scatter_points_cuda.cu:241-308
+ *   grad_feats.fill_(0)                                                    (:259)
+ *   sum : grad_feats[i] = grad_voxel[map[i]]                                (:121-124)
+ *   mean: grad_feats[i] = grad_voxel[map[i]] / count[map[i]]                (:125-130)
+ *   max : reduce_from[v][c] = min{ i : feats[i][c] == voxel_feats[v][c] }   (:135-160)
+ *         grad_feats[reduce_from[v][c]][c] = grad_voxel[v][c]               (:162-179) */
+ORACLE_API void oracle_dynamic_scatter_bwd(const float *grad_voxel_feats, const float *feats,
+                                           const float *voxel_feats, const int32_t *point2voxel,
+                                           const int32_t *voxel_count, int N, int M, int C,
+                                           int reduce_type, float *grad_feats) {
+  memset(grad_feats, 0, sizeof(float) * (size_t)N * C);
+  if (N == 0 || M == 0) return;
+  if (reduce_type == 0 || reduce_type == 1) {
+    for (int i = 0; i < N; ++i) {
+      int v = point2voxel[i];
+      if (v < 0) continue;
+      for (int ch = 0; ch < C; ++ch) {
+        float g = grad_voxel_feats[(size_t)v * C + ch];
+        grad_feats[(size_t)i * C + ch] = (reduce_type == 0) ? g : g / (float)voxel_count[v];
+      }
+    }
+  } else {
+    int32_t *from = (int32_t *)malloc(sizeof(int32_t) * (size_t)M * C);
+    for (size_t j = 0; j < (size_t)M * C; ++j) from[j] = N;
+    for (int i = 0; i < N; ++i) {
+      int v = point2voxel[i];
+      if (v < 0) continue;
+      for (int ch = 0; ch < C; ++ch) {
+        if (feats[(size_t)i * C + ch] == voxel_feats[(size_t)v * C + ch]) {
+          int32_t *f = from + (size_t)v * C + ch;
+          if (i < *f) *f = i;
+        }
+      }
+    }
+    for (int v = 0; v < M; ++v)
+      for (int ch = 0; ch < C; ++ch) {
+        int32_t src = from[(size_t)v * C + ch];
+        if (src < N) grad_feats[(size_t)src * C + ch] = grad_voxel_feats[(size_t)v * C + ch];
+      }
+    free(from);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BEV cell index + range mask + rank: BF/depth_lss.py:118-176 (bev_pool_aux), steps (1)-(4).
+ *   cell = ((p - (bx - dx/2)) / dx).long()   truncation toward zero (:129)
+ *   kept = 0 <= cell < nx on all three axes  (:141-148)
+ *   rank = x*(W*D*B) + y*(D*B) + z*B + b     with D=nx[2], W=nx[1] (:165-169)
+ * geom f32[Nprime,3] lidar-frame xyz, row-major; sample index = row / (Nprime/B).
+ * `origin[k]` = bx[k]-dx[k]/2 computed by the caller in fp32 exactly as torch does (tensor op).
+ * Outputs for ALL Nprime rows: cell i32[Nprime,4]=(x,y,z,b), kept u8[Nprime], rank i64[Nprime].
+ * torch .long() of an out-of-range/NaN float is UB; such rows are defined as not kept.
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API void oracle_bev_cells(const float *geom, int64_t nprime, int B, const float *origin,
+                                 const float *dx, const int32_t *nx, int32_t *cell, uint8_t *kept,
+                                 int64_t *rank) {
+  int64_t per = nprime / B;
+  for (int64_t i = 0; i < nprime; ++i) {
+    int32_t c[3];
+    int ok = 1;
+    for (int k = 0; k < 3; ++k) {
+      float q = (geom[i * 3 + k] - origin[k]) / dx[k];
+      if (!(q > -2147483648.0f && q < 2147483648.0f)) { ok = 0; c[k] = -1; continue; }
+      c[k] = (int32_t)q; /* truncation */
+      if (c[k] < 0 || c[k] >= nx[k]) ok = 0;
+    }
+    int32_t bi = (int32_t)(i / per);
+    cell[i * 4 + 0] = c[0]; cell[i * 4 + 1] = c[1]; cell[i * 4 + 2] = c[2]; cell[i * 4 + 3] = bi;
+    kept[i] = (uint8_t)ok;
+    int64_t W = nx[1], Dz = nx[2];
+    rank[i] = ok ? ((int64_t)c[0] * (W * Dz * B) + (int64_t)c[1] * (Dz * B) + (int64_t)c[2] * B + bi) : -1;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Frustum geometry: BF/depth_lss.py:68-112 (get_geometry).
+ *   points = frustum - post_trans                       (:82)
+ *   points = post_rots_inverse @ points                 (:83)
+ *   points = (x*z, y*z, z)                              (:85-91)
+ *   combine = camera2lidar_rots @ intrins_inverse       (:93)  -- computed by the caller
+ *   points = combine @ points ; points += c2l_trans     (:94-96)
+ *   points = extra_rots @ points ; points += extra_trans (:99-109; identity/zero when absent)
+ * The reference evaluates the 3x3 products through torch.matmul (BLAS batched GEMV; its
+ * association/FMA use is implementation-defined).  The restatement fixes the order to
+ * ((m0*p0 + m1*p1) + m2*p2) with every product and sum rounded to fp32 (no FMA), and the HIP
+ * kernel uses the identical order, so cells computed from it are bit-identical between the
+ * two.  Against the reference's own torch evaluation the result agrees to ~1 ulp (test:
+ * tests/test_oracle_golden.py::test_geometry_vs_reference).
+ * frustum f32[D*HW,3]; per camera (B*N): post_trans[3], post_rots_inv[9], combine[9], c2l_trans[3];
+ * per sample (B): extra_rots[9], extra_trans[3].  out f32[B*N*D*HW, 3].
+ * ------------------------------------------------------------------------------------------ */
+static inline void mat3_vec(const float *m, const float *p, float *o) {
+  for (int i = 0; i < 3; ++i) {
+    float a = m[i * 3 + 0] * p[0];
+    float b = m[i * 3 + 1] * p[1];
+    float c = m[i * 3 + 2] * p[2];
+    o[i] = (a + b) + c;
+  }
+}
+
+ORACLE_API void oracle_frustum_geometry(const float *frustum, int B, int N, int DHW,
+                                        const float *post_trans, const float *post_rots_inv,
+                                        const float *combine, const float *c2l_trans,
+                                        const float *extra_rots, const float *extra_trans,
+                                        float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < N; ++n) {
+      int cam = b * N + n;
+      for (int i = 0; i < DHW; ++i) {
+        float p[3], q[3];
+        for (int k = 0; k < 3; ++k) p[k] = frustum[(size_t)i * 3 + k] - post_trans[cam * 3 + k];
+        mat3_vec(post_rots_inv + cam * 9, p, q);
+        p[0] = q[0] * q[2]; p[1] = q[1] * q[2]; p[2] = q[2];
+        mat3_vec(combine + cam * 9, p, q);
+        for (int k = 0; k < 3; ++k) q[k] = q[k] + c2l_trans[cam * 3 + k];
+        mat3_vec(extra_rots + b * 9, q, p);
+        for (int k = 0; k < 3; ++k) p[k] = p[k] + extra_trans[b * 3 + k];
+        float *o = out + ((size_t)cam * DHW + i) * 3;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+      }
+    }
+}

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE itself.  Run in the build container only
+(needs /root/reference); the GPU box and the test-suite only read the committed .npz files.
+
+What is executed from the reference:
+  (A) its CPU voxelization extension, compiled unmodified from the sources in place by
+      oracle/build_ref.sh  ->  hard_voxelize / dynamic_voxelize outputs
+  (B) projects/BEVFusion/bevfusion/depth_lss.py, loaded BY PATH as python source.  Its two
+      imports that are not installable here are satisfied with inert placeholders:
+      `mmdet3d.registry.MODELS.register_module()` -> identity decorator (registration only),
+      `.ops.bev_pool` -> the CPU oracle (the reference's op is CUDA-only).  Everything that is
+      recorded as "reference output" below (frustum, geometry, bev_pool_aux cells / kept /
+      ranks, the python glue around the op) is computed by the reference's own code.
+
+Only data is stored: inputs are regenerated from seeds by the synthetic module (their sha256 is
+stored to detect drift), outputs are stored in full when small and as sha256 + statistics
+when large.
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+
+import bevfusion_amd  # noqa: E402,F401
+from bevfusion_amd import synthetic  # noqa: E402
+import oracle  # noqa: E402
+
+
+def sha(a):
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+# --------------------------------------------------------------------------------------- (A)
+def ref_hard_voxelize(v, pts, voxel_size, rng, max_points, max_voxels):
+    p = torch.from_numpy(pts)
+    voxels = p.new_zeros((max_voxels, max_points, p.shape[1]))
+    coors = p.new_zeros((max_voxels, 3), dtype=torch.int)
+    num = p.new_zeros((max_voxels,), dtype=torch.int)
+    n = v.hard_voxelize(p, voxels, coors, num, list(voxel_size), list(rng), max_points, max_voxels, 3, True)
+    return voxels[:n].numpy(), coors[:n].numpy(), num[:n].numpy()
+
+
+def ref_dynamic_voxelize(v, pts, voxel_size, rng):
+    p = torch.from_numpy(pts)
+    coors = p.new_zeros((p.shape[0], 3), dtype=torch.int)
+    v.dynamic_voxelize(p, coors, list(voxel_size), list(rng), 3)
+    return coors.numpy()
+
+
+def make_voxel_goldens():
+    import voxel_layer_ref as v
+    out = {}
+    # A1: the reference's only known-answer test (tests/test_models/test_task_modules/test_voxel/
+    # test_voxel_generator.py:7-20): seed 0, 20 uniform points, expected coors (zyx) / counts.
+    np.random.seed(0)
+    kat_pts = np.random.uniform(0, 4, (20, 3)).astype(np.float32)
+    vox, coors, num = ref_hard_voxelize(v, kat_pts, [5, 5, 1], [0, 0, 0, 20, 40, 4], 5, 20)
+    assert (coors[:, ::-1] == np.array([[2, 0, 0], [3, 0, 0], [0, 0, 0], [1, 0, 0]])).all()
+    assert (num == np.array([5, 5, 5, 3])).all()
+    out.update(kat_points=kat_pts, kat_voxels=vox, kat_coors=coors, kat_num=num)
+
+    # A2: cubic grid (where the reference's table indexing bug is harmless): 40k sweep
+    pts = synthetic.lidar_sweep(40000, seed=1000)
+    rng, vs = [-40.0, -40.0, -40.0, 40.0, 40.0, 40.0], [1.0, 1.0, 1.0]
+    vox, coors, num = ref_hard_voxelize(v, pts, vs, rng, 10, 20000)
+    out.update(cubic_in_sha=sha(pts), cubic_coors=coors, cubic_num=num, cubic_voxels_sha=sha(vox),
+               cubic_voxels_head=vox[:64])
+    # A3: cubic grid with a binding max_voxels cap and small max_points
+    vox, coors, num = ref_hard_voxelize(v, pts, [0.5, 0.5, 0.5], rng, 3, 3000)
+    out.update(cap_coors=coors, cap_num=num, cap_voxels_sha=sha(vox))
+    # A4: uniform stress points on a cubic grid (M ~ N), includes out-of-range points
+    upts = synthetic.uniform_points(20000, seed=7, rng_range=(-20, -20, -20, 20, 20, 20), margin=2.0)
+    vox, coors, num = ref_hard_voxelize(v, upts, [0.5, 0.5, 0.5], [-20, -20, -20, 20, 20, 20], 10, 30000)
+    out.update(uni_in_sha=sha(upts), uni_coors=coors, uni_num=num, uni_voxels_sha=sha(vox))
+    # A5: dynamic voxelization at the real nuScenes grid (the reference's CPU path is fine here)
+    N = synthetic.NUSC
+    dc = ref_dynamic_voxelize(v, pts, N["voxel_size"], N["point_cloud_range"])
+    out.update(dyn_nusc_coors=dc)
+    upts2 = synthetic.uniform_points(40000, seed=11)
+    out.update(dyn_uni_in_sha=sha(upts2),
+               dyn_uni_coors=ref_dynamic_voxelize(v, upts2, N["voxel_size"], N["point_cloud_range"]))
+    np.savez_compressed(os.path.join(HERE, "voxelization_ref.npz"), **out)
+    print("voxelization_ref.npz:", {k: getattr(val, "shape", val) for k, val in out.items()})
+
+
+# --------------------------------------------------------------------------------------- (B)
+def load_reference_depth_lss():
+    def oracle_bev_pool(feats, coords, ranks, B, D, H, W, is_training):
+        starts, lengths = oracle.intervals_from_ranks(ranks.numpy())
+        out = oracle.bev_pool_fwd(feats.numpy(), coords.int().numpy(), starts, lengths, int(B), int(D), int(H), int(W))
+        return torch.from_numpy(out).permute(0, 4, 1, 2, 3).contiguous()
+
+    class _Registry:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    m3d = types.ModuleType("mmdet3d")
+    reg = types.ModuleType("mmdet3d.registry")
+    reg.MODELS = _Registry()
+    m3d.registry = reg
+    sys.modules.setdefault("mmdet3d", m3d)
+    sys.modules.setdefault("mmdet3d.registry", reg)
+    pkg = types.ModuleType("refbev")
+    pkg.__path__ = []
+    ops = types.ModuleType("refbev.ops")
+    ops.bev_pool = oracle_bev_pool
+    sys.modules["refbev"] = pkg
+    sys.modules["refbev.ops"] = ops
+    path = os.path.join(REF, "projects/BEVFusion/bevfusion/depth_lss.py")
+    spec = importlib.util.spec_from_file_location("refbev.depth_lss", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["refbev.depth_lss"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def geometry_inputs(rig):
+    """The tensors BaseViewTransform.forward derives before get_geometry (depth_lss.py:240-262)."""
+    t = {k: torch.from_numpy(v) for k, v in rig.items()}
+    intrins = t["camera_intrinsics"][..., :3, :3]
+    post_rots = t["img_aug_matrix"][..., :3, :3]
+    post_trans = t["img_aug_matrix"][..., :3, 3]
+    c2l_rots = t["camera2lidar"][..., :3, :3]
+    c2l_trans = t["camera2lidar"][..., :3, 3]
+    extra_rots = t["lidar_aug_matrix"][..., :3, :3]
+    extra_trans = t["lidar_aug_matrix"][..., :3, 3]
+    return dict(c2l_rots=c2l_rots, c2l_trans=c2l_trans, intrins_inv=torch.inverse(intrins),
+                post_rots_inv=torch.inverse(post_rots), post_trans=post_trans, extra_rots=extra_rots,
+                extra_trans=extra_trans)
+
+
+def make_lss_goldens():
+    mod = load_reference_depth_lss()
+    N = synthetic.NUSC
+    out = {}
+    # B1: tiny view transform, 2 samples x 6 cameras, train-time lidar augmentation
+    tiny = dict(in_channels=16, out_channels=8, image_size=(64, 176), feature_size=(8, 22),
+                xbound=[-54.0, 54.0, 1.2], ybound=[-54.0, 54.0, 1.2], zbound=[-10.0, 10.0, 20.0],
+                dbound=[1.0, 61.0, 3.0])
+    vt = mod.LSSTransform(**tiny)
+    vt.eval()
+    rig = synthetic.camera_rig(batch=2, seed=5, train_aug=True)
+    # scale the image aug to the tiny image: 1600x900 -> 0.12 -> 192x108, crop to 176x64
+    rig["img_aug_matrix"][..., 0, 0] = 0.12
+    rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3] = -8.0
+    rig["img_aug_matrix"][..., 1, 3] = -44.0
+    gi = geometry_inputs(rig)
+    with torch.no_grad():
+        geom = vt.get_geometry(gi["c2l_rots"], gi["c2l_trans"], gi["intrins_inv"], gi["post_rots_inv"],
+                               gi["post_trans"], extra_rots=gi["extra_rots"], extra_trans=gi["extra_trans"])
+        geom_feats, kept, ranks, indices = vt.bev_pool_aux(geom)
+        g = torch.Generator().manual_seed(123)
+        B, Ncam, D, fH, fW = geom.shape[:5]
+        x = torch.randn(B, Ncam, D, fH, fW, tiny["out_channels"], generator=g)
+        bev = vt.bev_pool(x, geom)   # reference glue + oracle op
+    out.update(tiny_frustum=vt.frustum.detach().numpy(), tiny_geom=geom.numpy(),
+               tiny_geom_feats=geom_feats.numpy().astype(np.int32), tiny_kept=kept.numpy(),
+               tiny_ranks=ranks.numpy(), tiny_bev=bev.numpy(), tiny_x_sha=sha(x.numpy()),
+               tiny_dx=vt.dx.detach().numpy(), tiny_bx=vt.bx.detach().numpy(), tiny_nx=vt.nx.detach().numpy())
+    for k, v in rig.items():
+        out["tiny_rig_" + k] = v
+
+    # B2: full nuScenes-size geometry, eval aug, B=1: hashes + statistics only
+    full = dict(in_channels=256, out_channels=80, image_size=N["image_size"], feature_size=N["feature_size"],
+                xbound=N["xbound"], ybound=N["ybound"], zbound=N["zbound"], dbound=N["dbound"])
+    vt = mod.LSSTransform(**full)
+    rig = synthetic.camera_rig(batch=1)
+    gi = geometry_inputs(rig)
+    with torch.no_grad():
+        geom = vt.get_geometry(gi["c2l_rots"], gi["c2l_trans"], gi["intrins_inv"], gi["post_rots_inv"],
+                               gi["post_trans"], extra_rots=gi["extra_rots"], extra_trans=gi["extra_trans"])
+        geom_feats, kept, ranks, indices = vt.bev_pool_aux(geom)
+    starts, lengths = oracle.intervals_from_ranks(ranks.numpy())
+    out.update(full_frustum_sha=sha(vt.frustum.detach().numpy()), full_geom_sha=sha(geom.numpy()),
+               full_geom_sample=geom.numpy().reshape(-1, 3)[::997].copy(),
+               full_kept_sha=sha(kept.numpy()), full_ranks_sha=sha(ranks.numpy()),
+               full_geom_feats_sha=sha(geom_feats.numpy().astype(np.int32)),
+               full_counts=np.array([kept.numel(), int(kept.sum()), len(starts), int(lengths.max()),
+                                     int(np.median(lengths))], np.int64),
+               full_dx=vt.dx.detach().numpy(), full_bx=vt.bx.detach().numpy(), full_nx=vt.nx.detach().numpy())
+    np.savez_compressed(os.path.join(HERE, "lss_ref.npz"), **out)
+    print("lss_ref.npz: counts (N', kept, intervals, max len, median len) =", out["full_counts"])
+
+
+if __name__ == "__main__":
+    make_voxel_goldens()
+    make_lss_goldens()
