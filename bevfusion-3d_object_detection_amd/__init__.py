@@ -15,5 +15,5 @@ __version__ = "0.1.0"
 
 def build(force: bool = False):
     """Compile csrc/*.hip for gfx950 into csrc/libbevfusion_hip.so (in-tree)."""
-    from . import build as _build
-    return _build.build(force=force)
+    import importlib
+    return importlib.import_module(__name__ + "._build").build(force=force)

@@ -20,6 +20,8 @@ _c_sz = ctypes.c_size_t
 SIGNATURES = {
     "bfhip_abi_version": (_c_int, []),
     "bfhip_last_error": (ctypes.c_char_p, []),
+    "bfhip_profile_enable": (None, [_c_int]),
+    "bfhip_profile_read": (_c_int, [_c_int, _c_vp, _c_vp, _c_int]),
     "bfhip_bev_pool_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 7 + [_c_vp, _c_vp]),
     "bfhip_bev_pool_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 8 + [_c_vp, _c_vp]),
     "bfhip_dynamic_voxelize": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
@@ -75,3 +77,20 @@ def require_cuda(t, name):
         raise RuntimeError("%s must be a CUDA(HIP) tensor; this build has no CPU path" % name)
     if not t.is_contiguous():
         raise RuntimeError("%s must be contiguous" % name)
+
+
+OPS = dict(bev_pool_fwd=0, bev_pool_bwd=1, hard_voxelize=2, dynamic_voxelize=3, lift_splat_fwd=4, lift_splat_bwd=5,
+           spconv_fwd=6, spconv_bwd=7, rulebook=8, bev_aux=9, scatter_fwd=10, scatter_bwd=11)
+
+
+def profile_enable(on=True):
+    load().bfhip_profile_enable(1 if on else 0)
+
+
+def profile_read(op, reset=True):
+    """(sum_ms, count) of the HIP-event pairs recorded around op's dominant kernel."""
+    s = ctypes.c_double(0.0)
+    c = ctypes.c_longlong(0)
+    check(load().bfhip_profile_read(OPS[op] if isinstance(op, str) else op, ctypes.byref(s), ctypes.byref(c),
+                                    1 if reset else 0), "profile_read")
+    return s.value, c.value

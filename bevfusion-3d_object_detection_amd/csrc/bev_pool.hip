@@ -135,6 +135,8 @@ BFHIP_EXPORT int bfhip_bev_pool_fwd(const float *x, const int32_t *geom, const i
   if (hipMemsetAsync(out, 0, out_bytes, stream) != hipSuccess) return check_launch("bev_pool_fwd memset");
   if (m == 0 || n == 0) return BFHIP_OK;
   BFHIP_REQUIRE(x && geom && starts && lengths, "bev_pool_fwd: null input");
+  ProfScope ps;
+  prof_begin(BFHIP_OP_BEV_POOL_FWD, stream, &ps);
   if (vec4_ok(c, x, out)) {
     int cq = c / 4, groups = kWave / cq;
     long long waves = ((long long)m + groups - 1) / groups;
@@ -147,6 +149,7 @@ BFHIP_EXPORT int bfhip_bev_pool_fwd(const float *x, const int32_t *geom, const i
     hipLaunchKernelGGL(bev_pool_fwd_scalar, dim3(blocks), dim3(256), 0, stream, x,
                        (const int4 *)geom, starts, lengths, out, m, c, d, h, w, m_dev);
   }
+  prof_end(&ps);
   return check_launch("bev_pool_fwd");
 }
 
@@ -167,6 +170,8 @@ BFHIP_EXPORT int bfhip_bev_pool_bwd(const float *out_grad, const int32_t *geom,
   }
   if (m == 0) return BFHIP_OK;
   BFHIP_REQUIRE(out_grad && geom && starts && lengths, "bev_pool_bwd: null input");
+  ProfScope ps;
+  prof_begin(BFHIP_OP_BEV_POOL_BWD, stream, &ps);
   if (vec4_ok(c, out_grad, x_grad)) {
     int cq = c / 4, groups = kWave / cq;
     long long waves = ((long long)m + groups - 1) / groups;
@@ -179,5 +184,6 @@ BFHIP_EXPORT int bfhip_bev_pool_bwd(const float *out_grad, const int32_t *geom,
     hipLaunchKernelGGL(bev_pool_bwd_scalar, dim3(blocks), dim3(256), 0, stream, out_grad,
                        (const int4 *)geom, starts, lengths, x_grad, m, c, d, h, w, m_dev);
   }
+  prof_end(&ps);
   return check_launch("bev_pool_bwd");
 }

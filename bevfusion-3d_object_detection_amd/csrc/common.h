@@ -24,6 +24,12 @@ inline int check_launch(const char *what) {
   return BFHIP_OK;
 }
 
+// optional profiler (capi.hip): events on the op's stream around its dominant kernel
+struct ProfScope { bool active; int op; hipStream_t stream; hipEvent_t a, b; };
+bool prof_enabled();
+void prof_begin(int op, hipStream_t s, ProfScope *sc);
+void prof_end(ProfScope *sc);
+
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -344,6 +344,8 @@ BFHIP_EXPORT int bfhip_hard_voxelize(const float *points, int n, int f, float *v
   int *lists = ws.take<int>(nlist);
   if (!ws.ok()) { set_error("hard_voxelize: workspace carve failed"); return BFHIP_E_WORKSPACE; }
 
+  ProfScope ps;
+  prof_begin(BFHIP_OP_HARD_VOXELIZE, stream, &ps);
   int init_blocks = ceil_div(cap > nlist ? cap : nlist, 256);
   if (init_blocks > 2048) init_blocks = 2048;
   hipLaunchKernelGGL(vox_init_kernel, dim3(init_blocks), dim3(256), 0, stream, keys, first, count,
@@ -362,5 +364,6 @@ BFHIP_EXPORT int bfhip_hard_voxelize(const float *points, int n, int f, float *v
   long long total = nlist * f;
   hipLaunchKernelGGL(vox_scatter_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, points,
                      f, lists, voxel_num_dev, max_points, voxels, total);
+  prof_end(&ps);
   return check_launch("hard_voxelize");
 }

@@ -38,9 +38,31 @@ extern "C" {
 #define BFHIP_REDUCE_MEAN 1
 #define BFHIP_REDUCE_MAX 2
 
+/* op ids of the optional profiler */
+#define BFHIP_OP_BEV_POOL_FWD 0
+#define BFHIP_OP_BEV_POOL_BWD 1
+#define BFHIP_OP_HARD_VOXELIZE 2 /* whole 7-launch pipeline */
+#define BFHIP_OP_DYNAMIC_VOXELIZE 3
+#define BFHIP_OP_LIFT_SPLAT_FWD 4
+#define BFHIP_OP_LIFT_SPLAT_BWD 5
+#define BFHIP_OP_SPCONV_FWD 6
+#define BFHIP_OP_SPCONV_BWD 7
+#define BFHIP_OP_RULEBOOK 8
+#define BFHIP_OP_BEV_AUX 9
+#define BFHIP_OP_SCATTER_FWD 10
+#define BFHIP_OP_SCATTER_BWD 11
+#define BFHIP_OP_COUNT 16
+
 int bfhip_abi_version(void);
 /* thread-local, valid until the next failing call on the same thread */
 const char *bfhip_last_error(void);
+
+/* Optional profiler used by bench.py for the roofline line: when enabled, every entry point
+ * records a HIP event pair ON ITS OWN STREAM around its dominant kernel launch (memsets and
+ * helper launches excluded).  bfhip_profile_read() synchronises the recorded events (the only
+ * call in this library that blocks) and returns the accumulated milliseconds and launch count. */
+void bfhip_profile_enable(int on);
+int bfhip_profile_read(int op, double *sum_ms_host, long long *count_host, int reset);
 
 /* ---------------------------------------------------------------------------------------
  * bev_pool  (replaces bev_pool_ext.bev_pool_forward / bev_pool_backward,
