@@ -1,0 +1,410 @@
+"""Host mirror of projects/BEVFusion/bevfusion/depth_lss.py (view transform of the camera branch).
+
+Same class and method names as the reference (`BaseViewTransform`, `LSSTransform`,
+`BaseDepthTransform`, `DepthLSSTransform`; `create_frustum`, `get_geometry`, `bev_pool_aux`,
+`bev_pool`, `bev_pool_precomputed`, `get_cam_feats`, `forward`).  What differs is where the work
+happens:
+
+  * geometry -> cell -> rank -> stable sort -> intervals run in ONE sync-free device plan
+    (`BevPlan`, csrc/lift_splat.hip: bfhip_bev_plan) instead of torch glue with an int64 argsort,
+    boolean-mask syncs and a materialised [B,N,D,H,W,3] tensor (reference :68-176);
+  * the depth (x) feature outer product and the two gathers are fused into the pooling kernel
+    (`lift_splat`, bfhip_lift_splat_fwd/bwd); the [N',C] tensor (638 MB/sample fp32) never exists.
+
+`bev_pool(x, geom)` / `bev_pool_precomputed(...)` keep the reference's op-boundary semantics for
+callers that hand over a materialised x.
+"""
+from typing import Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from .ops import bev_pool
+from .registry import MODELS
+
+
+def gen_dx_bx(xbound, ybound, zbound):
+    """(reference :14-18) dx = step, bx = first cell centre, nx = int((hi-lo)/step)."""
+    rows = [xbound, ybound, zbound]
+    dx = torch.Tensor([row[2] for row in rows])
+    bx = torch.Tensor([row[0] + row[2] / 2.0 for row in rows])
+    nx = torch.LongTensor([int((row[1] - row[0]) / row[2]) for row in rows])
+    return dx, bx, nx
+
+
+class BevPlan:
+    """Device-resident result of bfhip_bev_plan for one batch of calibrations.
+
+    sorted_pd u32[N'], starts/lengths/cell_of_interval i32[mmax], counts i32[2]={n_kept, m},
+    cell_of_point i32[N'] and, when `with_reference_outputs`, the arrays the reference's
+    bev_pool_aux returns (geom_feats i32[N',4], ranks i64[N'], kept bool[N']).
+    """
+
+    def __init__(self, B, N, D, HW, nx, device, with_reference_outputs=False, with_geometry=False):
+        self.B, self.N, self.D, self.HW = B, N, D, HW
+        self.nx = [int(v) for v in nx]
+        self.nprime = B * N * D * HW
+        self.out_cells = B * self.nx[2] * self.nx[0] * self.nx[1]
+        self.mmax = min(self.nprime, self.out_cells)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.sorted_pd = torch.empty(self.nprime, **i32)
+        self.starts = torch.empty(self.mmax, **i32)
+        self.lengths = torch.empty(self.mmax, **i32)
+        self.cell_of_interval = torch.empty(self.mmax, **i32)
+        self.counts = torch.zeros(2, **i32)
+        self.cell_of_point = torch.empty(self.nprime, **i32)
+        self.geom_sorted = torch.empty((self.nprime, 4), **i32) if with_reference_outputs else None
+        self.ranks_sorted = torch.empty(self.nprime, dtype=torch.int64, device=device) if with_reference_outputs else None
+        self.kept = torch.empty(self.nprime, dtype=torch.uint8, device=device) if with_reference_outputs else None
+        self.geom_xyz = torch.empty((self.nprime, 3), dtype=torch.float32, device=device) if with_geometry else None
+        nbytes = _lib.load().bfhip_bev_plan_workspace_bytes(self.nprime, self.out_cells)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def build(self, frustum, post_trans, post_rots_inv, combine, c2l_trans, extra_rots, extra_trans, origin, dx):
+        """All tensor arguments on the device, fp32, contiguous; origin/dx python floats (host)."""
+        f32 = lambda t: t.contiguous().float()
+        args = [f32(frustum), f32(post_trans), f32(post_rots_inv), f32(combine), f32(c2l_trans), f32(extra_rots),
+                f32(extra_trans)]
+        import ctypes
+        nx_host = (ctypes.c_int32 * 3)(*self.nx)
+        with torch.cuda.device(self.sorted_pd.device):
+            rc = _lib.load().bfhip_bev_plan(
+                *[_lib.ptr(a) for a in args], self.B, self.N, self.D, self.HW, _lib.host_f32(origin), _lib.host_f32(dx),
+                nx_host, _lib.ptr(self.sorted_pd), _lib.ptr(self.starts), _lib.ptr(self.lengths),
+                _lib.ptr(self.cell_of_interval), _lib.ptr(self.counts), _lib.ptr(self.cell_of_point),
+                _lib.ptr(self.geom_sorted), _lib.ptr(self.ranks_sorted), _lib.ptr(self.kept), _lib.ptr(self.geom_xyz),
+                self.mmax, _lib.ptr(self.workspace), self.workspace.numel(), _lib.stream_of(self.sorted_pd))
+        _lib.check(rc, "bev_plan")
+        self._keepalive = args
+        return self
+
+
+class _LiftSplat(torch.autograd.Function):
+    """out[b,z,x,y,:] = sum over the cell's frustum points of depth[p,d] * feat[p,:]."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, plan):
+        # depth [P, D] pixel-major, feat [P, C] pixel-major (any pitch, last dim contiguous)
+        assert depth.dim() == 2 and feat.dim() == 2 and depth.stride(1) == 1 and feat.stride(1) == 1
+        assert depth.dtype == torch.float32 and feat.dtype == torch.float32
+        P, C = feat.shape
+        assert P == plan.B * plan.N * plan.HW and depth.shape == (P, plan.D)
+        out = torch.empty((plan.B, plan.nx[2], plan.nx[0], plan.nx[1], C), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            rc = _lib.load().bfhip_lift_splat_fwd(
+                _lib.ptr(depth), depth.stride(0), _lib.ptr(feat), feat.stride(0), _lib.ptr(plan.sorted_pd),
+                _lib.ptr(plan.starts), _lib.ptr(plan.lengths), _lib.ptr(plan.cell_of_interval), _lib.ptr(plan.counts),
+                plan.mmax, C, plan.out_cells, _lib.ptr(out), _lib.stream_of(feat))
+        _lib.check(rc, "lift_splat_fwd")
+        ctx.save_for_backward(depth, feat)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        depth, feat = ctx.saved_tensors
+        plan = ctx.plan
+        out_grad = out_grad.contiguous()
+        P, C = feat.shape
+        d_depth = torch.empty((P, plan.D), dtype=torch.float32, device=feat.device)
+        d_feat = torch.empty((P, C), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            rc = _lib.load().bfhip_lift_splat_bwd(
+                _lib.ptr(out_grad), _lib.ptr(depth), depth.stride(0), _lib.ptr(feat), feat.stride(0),
+                _lib.ptr(plan.cell_of_point), plan.B * plan.N, plan.D, plan.HW, C, _lib.ptr(d_depth), plan.D,
+                _lib.ptr(d_feat), C, _lib.stream_of(feat))
+        _lib.check(rc, "lift_splat_bwd")
+        return d_depth, d_feat, None
+
+
+def lift_splat(depth, feat, plan):
+    """depth f32[P,D], feat f32[P,C] (pixel-major) -> BEV f32[B, nz, nx, ny, C]."""
+    return _LiftSplat.apply(depth, feat, plan)
+
+
+class BaseViewTransform(nn.Module):
+
+    def __init__(self, in_channels: int, out_channels: int, image_size: Tuple[int, int],
+                 feature_size: Tuple[int, int], xbound, ybound, zbound, dbound) -> None:
+        super().__init__()
+        self.in_channels = in_channels
+        self.image_size = image_size
+        self.feature_size = feature_size
+        self.xbound, self.ybound, self.zbound, self.dbound = xbound, ybound, zbound, dbound
+        dx, bx, nx = gen_dx_bx(xbound, ybound, zbound)
+        self.dx = nn.Parameter(dx, requires_grad=False)
+        self.bx = nn.Parameter(bx, requires_grad=False)
+        self.nx = nn.Parameter(nx, requires_grad=False)
+        self.C = out_channels
+        self.frustum = self.create_frustum()
+        self.D = self.frustum.shape[0]
+        self.fp16_enabled = False
+        # host copies for the plan (no per-step D2H)
+        self._nx_host = [int(v) for v in nx]
+        self._dx_host = [float(v) for v in dx]
+        self._origin_host = [float(v) for v in (bx - dx / 2.0)]  # fp32 tensor arithmetic, as the reference
+
+    def create_frustum(self):
+        """(reference :53-66) [D, fH, fW, 3] = (pixel x, pixel y, depth)."""
+        iH, iW = self.image_size
+        fH, fW = self.feature_size
+        ds = torch.arange(*self.dbound, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+        D = ds.shape[0]
+        xs = torch.linspace(0, iW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+        ys = torch.linspace(0, iH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+        return nn.Parameter(torch.stack((xs, ys, ds), -1), requires_grad=False)
+
+    # ------------------------------------------------------------------ device plan
+    def make_plan(self, camera2lidar_rots, camera2lidar_trans, intrins_inverse, post_rots_inverse, post_trans,
+                  extra_rots=None, extra_trans=None, with_reference_outputs=False, with_geometry=False):
+        B, N, _ = camera2lidar_trans.shape
+        dev = camera2lidar_trans.device
+        fH, fW = self.feature_size
+        plan = BevPlan(B, N, self.D, fH * fW, self._nx_host, dev, with_reference_outputs, with_geometry)
+        combine = camera2lidar_rots.matmul(intrins_inverse)  # (reference :93)
+        if extra_rots is None:
+            extra_rots = torch.eye(3, device=dev).expand(B, 3, 3)
+        if extra_trans is None:
+            extra_trans = torch.zeros(B, 3, device=dev)
+        return plan.build(self.frustum.view(-1, 3), post_trans.reshape(B * N, 3), post_rots_inverse.reshape(B * N, 9),
+                          combine.reshape(B * N, 9), camera2lidar_trans.reshape(B * N, 3), extra_rots.reshape(B, 9),
+                          extra_trans.reshape(B, 3), self._origin_host, self._dx_host)
+
+    def get_geometry(self, camera2lidar_rots, camera2lidar_trans, intrins_inverse, post_rots_inverse, post_trans,
+                     **kwargs):
+        """(reference :68-112) materialised lidar-frame frustum [B,N,D,fH,fW,3]; computed by the plan kernel."""
+        B, N, _ = camera2lidar_trans.shape
+        plan = self.make_plan(camera2lidar_rots, camera2lidar_trans, intrins_inverse, post_rots_inverse, post_trans,
+                              kwargs.get("extra_rots"), kwargs.get("extra_trans"), with_geometry=True)
+        fH, fW = self.feature_size
+        return plan.geom_xyz.view(B, N, self.D, fH, fW, 3)
+
+    def get_cam_feats(self, x):
+        raise NotImplementedError
+
+    def bev_pool_aux(self, geom_feats):
+        """(reference :118-176) geom [B,N,D,H,W,3] -> (geom_feats int[nk,4], kept bool[N'], ranks int64[nk],
+        indices int64[nk]).  Kept for API parity (materialised geometry in, one host sync for nk);
+        the sort is stable, so `indices` is deterministic (the reference's argsort is not)."""
+        B, N, D, H, W, C = geom_feats.shape
+        assert C == 3
+        cells = ((geom_feats - (self.bx - self.dx / 2.0)) / self.dx).long().view(-1, 3)
+        nprime = cells.shape[0]
+        batch_ix = torch.arange(nprime, device=cells.device) // (nprime // B)
+        cells = torch.cat((cells, batch_ix[:, None]), 1)
+        kept = ((cells[:, :3] >= 0) & (cells[:, :3] < self.nx)).all(1)
+        cells = cells[kept]
+        Dz, Hx, Wy = self.nx[2], self.nx[0], self.nx[1]
+        ranks = cells[:, 0] * (Wy * Dz * B) + cells[:, 1] * (Dz * B) + cells[:, 2] * B + cells[:, 3]
+        ranks, indices = torch.sort(ranks, stable=True)
+        return cells[indices], kept, ranks, indices
+
+    def bev_pool(self, x, geom_feats):
+        """(reference :179-204) op-boundary path: x [B,N,D,H,W,C] materialised, geom [B,N,D,H,W,3]."""
+        B, N, D, H, W, C = x.shape
+        x = x.reshape(B * N * D * H * W, C)
+        geom_feats, kept, ranks, indices = self.bev_pool_aux(geom_feats)
+        return self.bev_pool_precomputed(x.view(B, N, D, H, W, C), geom_feats, kept, ranks, indices)
+
+    def bev_pool_precomputed(self, x, geom_feats, kept, ranks, indices):
+        """(reference :206-223)"""
+        B, N, D, H, W, C = x.shape
+        x = x.reshape(B * N * D * H * W, C)[kept]
+        assert x.shape[0] == geom_feats.shape[0]
+        x = x[indices]
+        x = bev_pool(x, geom_feats, ranks, B, self.nx[2], self.nx[0], self.nx[1], self.training)
+        return torch.cat(x.unbind(dim=2), 1)  # collapse Z: [B, C*nz, nx, ny]
+
+    # ------------------------------------------------------------------ fused path
+    def lift_splat_bev(self, depth, feat, plan):
+        """depth [BN, D, fH, fW], feat [BN, C, fH, fW] (the reference's layouts, :699-701) ->
+        [B, C*nz, nx, ny], identical to bev_pool(depth (x) feat, geom)."""
+        BN, D, fH, fW = depth.shape
+        C = feat.shape[1]
+        depth_pm = depth.permute(0, 2, 3, 1).reshape(BN * fH * fW, D)  # free if channels_last
+        feat_pm = feat.permute(0, 2, 3, 1).reshape(BN * fH * fW, C)
+        if depth_pm.stride(1) != 1:
+            depth_pm = depth_pm.contiguous()
+        if feat_pm.stride(1) != 1 or feat_pm.stride(0) % 4 or feat_pm.data_ptr() % 16:
+            feat_pm = feat_pm.contiguous()
+        out = lift_splat(depth_pm.float(), feat_pm.float(), plan)  # [B, nz, nx, ny, C]
+        out = out.permute(0, 4, 1, 2, 3)  # [B, C, nz, nx, ny]
+        return torch.cat(out.unbind(dim=2), 1).contiguous()
+
+    def _calibration(self, camera_intrinsics, camera2lidar, img_aug_matrix, lidar_aug_matrix):
+        intrins = camera_intrinsics[..., :3, :3]
+        post_rots = img_aug_matrix[..., :3, :3]
+        return dict(camera2lidar_rots=camera2lidar[..., :3, :3], camera2lidar_trans=camera2lidar[..., :3, 3],
+                    intrins_inverse=torch.inverse(intrins), post_rots_inverse=torch.inverse(post_rots),
+                    post_trans=img_aug_matrix[..., :3, 3], extra_rots=lidar_aug_matrix[..., :3, :3],
+                    extra_trans=lidar_aug_matrix[..., :3, 3])
+
+    def forward(self, img, points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix, lidar_aug_matrix,
+                metas=None, camera_intrinsics_inverse=None, img_aug_matrix_inverse=None,
+                lidar_aug_matrix_inverse=None, geom_feats_precomputed=None):
+        """(reference :225-270) geom_feats_precomputed may be a BevPlan (fused path) or the reference's
+        (geom_feats, kept, ranks, indices) tuple (op-boundary path)."""
+        if isinstance(geom_feats_precomputed, BevPlan):
+            plan = geom_feats_precomputed
+        elif geom_feats_precomputed is not None:
+            geom_feats, kept, ranks, indices = geom_feats_precomputed[:4]
+            return self.bev_pool_precomputed(self.get_cam_feats(img), geom_feats, kept, ranks, indices)
+        else:
+            plan = self.make_plan(**self._calibration(camera_intrinsics, camera2lidar, img_aug_matrix, lidar_aug_matrix))
+        depth, feat = self.get_depth_and_feat(img)
+        return self.lift_splat_bev(depth, feat, plan)
+
+
+@MODELS.register_module()
+class LSSTransform(BaseViewTransform):
+    """(reference :273-339) depthnet = 1x1 conv producing D depth logits + C features."""
+
+    def __init__(self, in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound,
+                 downsample: int = 1) -> None:
+        super().__init__(in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound)
+        self.depthnet = nn.Conv2d(in_channels, self.D + self.C, 1)
+        self.downsample = _make_downsample(out_channels, downsample)
+
+    def get_depth_and_feat(self, x):
+        B, N, C, fH, fW = x.shape
+        x = self.depthnet(x.view(B * N, C, fH, fW))
+        return x[:, :self.D].softmax(dim=1), x[:, self.D:self.D + self.C]
+
+    def get_cam_feats(self, x):
+        """Materialised [B,N,D,fH,fW,C] (reference :320-334), for the op-boundary path."""
+        B, N = x.shape[:2]
+        depth, feat = self.get_depth_and_feat(x)
+        fH, fW = depth.shape[-2:]
+        out = depth.unsqueeze(1) * feat.unsqueeze(2)
+        return out.view(B, N, self.C, self.D, fH, fW).permute(0, 1, 3, 4, 5, 2)
+
+    def forward(self, *args, **kwargs):
+        return self.downsample(super().forward(*args, **kwargs))
+
+
+def _make_downsample(out_channels, downsample):
+    if downsample <= 1:
+        return nn.Identity()
+    assert downsample == 2, downsample
+    return nn.Sequential(
+        nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU(True),
+        nn.Conv2d(out_channels, out_channels, 3, stride=downsample, padding=1, bias=False),
+        nn.BatchNorm2d(out_channels), nn.ReLU(True),
+        nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU(True))
+
+
+class BaseDepthTransform(BaseViewTransform):
+    """(reference :342-551) adds the sparse LiDAR depth image as an input of get_cam_feats."""
+
+    def rasterise_depth(self, img, points, lidar2image, img_aug_matrix, lidar_aug_matrix, lidar_aug_matrix_inverse=None):
+        """LiDAR points -> sparse depth images [B, N, 1, iH, iW] (reference :363-449).  Points are not
+        modified (the reference mutates its argument in place).  Duplicate pixels
+        keep one of the colliding depths (unspecified which, as in the reference :410-417)."""
+        if lidar_aug_matrix_inverse is None:
+            lidar_aug_matrix_inverse = torch.inverse(lidar_aug_matrix)
+        B = len(points)
+        N = img.shape[1]
+        iH, iW = self.image_size
+        depth = torch.zeros(B, N, 1, iH, iW, device=points[0].device, dtype=torch.float32)
+        for b in range(B):
+            cur = points[b][:, :3] - lidar_aug_matrix[b, :3, 3]
+            cur = lidar_aug_matrix_inverse[b, :3, :3].matmul(cur.transpose(1, 0))
+            cur = lidar2image[b, :, :3, :3].matmul(cur) + lidar2image[b, :, :3, 3].reshape(-1, 3, 1)
+            dist = cur[:, 2, :]
+            z = torch.clamp(dist, 1e-5, 1e5)
+            cur = torch.cat((cur[:, :2, :] / z.unsqueeze(1), z.unsqueeze(1)), 1)
+            cur = img_aug_matrix[b, :, :3, :3].matmul(cur) + img_aug_matrix[b, :, :3, 3].reshape(-1, 3, 1)
+            rc = cur[:, :2, :].transpose(1, 2)[..., [1, 0]]  # (row, col)
+            on_img = (rc[..., 0] < iH) & (rc[..., 0] >= 0) & (rc[..., 1] < iW) & (rc[..., 1] >= 0)
+            rcl = rc.long()
+            flat = (torch.arange(N, device=rc.device).view(N, 1) * (iH * iW) + rcl[..., 0] * iW + rcl[..., 1])
+            flat = torch.where(on_img, flat, torch.full_like(flat, N * iH * iW))  # dump slot for misses
+            upd = torch.zeros(N * iH * iW + 1, device=rc.device, dtype=torch.float32)
+            upd.scatter_(0, flat.reshape(-1), dist.reshape(-1))
+            depth[b] = upd[:-1].view(N, 1, iH, iW)
+        return depth
+
+    def forward(self, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix,
+                metas=None, camera_intrinsics_inverse=None, img_aug_matrix_inverse=None,
+                lidar_aug_matrix_inverse=None, geom_feats_precomputed=None):
+        depth_img = self.rasterise_depth(img, points, lidar2image, img_aug_matrix, lidar_aug_matrix,
+                                         lidar_aug_matrix_inverse)
+        if isinstance(geom_feats_precomputed, BevPlan):
+            plan = geom_feats_precomputed
+        else:
+            plan = self.make_plan(**self._calibration(cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix))
+        depth, feat, est_depth_distr, gt_depth_distr, counts_3d = self.get_depth_and_feat(img, depth_img)
+        x = self.lift_splat_bev(depth, feat, plan)
+        if self.training:
+            # depth cross-entropy on cells that hold LiDAR returns (reference :540-547)
+            mask_flat = counts_3d.sum(dim=-1).view(-1) > 0
+            gt = gt_depth_distr.view(-1, self.D)
+            est = est_depth_distr.reshape(-1, self.D)
+            cross_ent = -torch.sum(gt * torch.log(est + 1e-8), dim=-1)
+            depth_loss = torch.sum(cross_ent * mask_flat.float()) / (mask_flat.sum() + 1e-8)
+        else:
+            depth_loss = 0.0
+        return x, depth_loss
+
+
+@MODELS.register_module()
+class DepthLSSTransform(BaseDepthTransform):
+    """(reference :555-733) dtransform on the sparse depth image + depthnet on cat(depth feats, image feats)."""
+
+    def __init__(self, in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound,
+                 downsample: int = 1) -> None:
+        super().__init__(in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound)
+        self.dtransform = nn.Sequential(
+            nn.Conv2d(1, 8, 1), nn.BatchNorm2d(8), nn.ReLU(True),
+            nn.Conv2d(8, 32, 5, stride=4, padding=2), nn.BatchNorm2d(32), nn.ReLU(True),
+            nn.Conv2d(32, 64, 5, stride=2, padding=2), nn.BatchNorm2d(64), nn.ReLU(True))
+        self.depthnet = nn.Sequential(
+            nn.Conv2d(in_channels + 64, in_channels, 3, padding=1), nn.BatchNorm2d(in_channels), nn.ReLU(True),
+            nn.Conv2d(in_channels, in_channels, 3, padding=1), nn.BatchNorm2d(in_channels), nn.ReLU(True),
+            nn.Conv2d(in_channels, self.D + self.C, 1))
+        self.downsample = _make_downsample(out_channels, downsample)
+
+    def gt_depth_distribution(self, d, B, N):
+        """Histogram of the sparse depth image over (feature cell, depth bin) (reference :636-686)."""
+        BN = B * N
+        h, w = self.image_size
+        fH, fW = self.feature_size
+        dev = d.device
+        rows = torch.arange(h, device=dev).view(1, -1, 1) // (h // fH)
+        cols = torch.arange(w, device=dev).view(1, 1, -1) // (w // fW)
+        cam = torch.arange(BN, device=dev).view(-1, 1, 1)
+        cell_id = (cam * fH * fW + rows * fW + cols).view(-1)
+        lo, hi, step = self.dbound
+        bins = ((d.clamp(min=lo, max=hi - 0.5 * step) + 0.5 * step - lo) / step).long().view(-1)
+        counts = torch.zeros(BN * fH * fW * self.D, dtype=torch.float, device=dev)
+        counts.scatter_add_(0, cell_id * self.D + bins, torch.ones_like(bins, dtype=torch.float))
+        counts_3d = counts.view(B, N, fH, fW, self.D)
+        counts_3d[..., 0] = 0.0
+        return counts_3d / (counts_3d.sum(dim=-1, keepdim=True) + 1e-8), counts_3d
+
+    def get_depth_and_feat(self, x, d):
+        B, N, C, fH, fW = x.shape
+        BN = B * N
+        d = d.view(BN, *d.shape[2:])
+        x = x.view(BN, C, fH, fW)
+        gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
+        x = self.depthnet(torch.cat([self.dtransform(d), x], dim=1))
+        depth = x[:, :self.D].softmax(dim=1)
+        est_depth_distr = depth.permute(0, 2, 3, 1).reshape(B, N, fH, fW, self.D)
+        if self.training:
+            depth_aux = gt_depth_distr.view(BN, fH, fW, self.D).permute(0, 3, 1, 2)
+            depth = depth + (torch.maximum(depth_aux, depth) - depth).detach()  # straight-through (reference :702-706)
+        return depth, x[:, self.D:self.D + self.C], est_depth_distr, gt_depth_distr, counts_3d
+
+    def get_cam_feats(self, x, d):
+        """Materialised outer product + aux outputs (reference :624-727)."""
+        B, N = x.shape[:2]
+        depth, feat, est, gt, counts = self.get_depth_and_feat(x, d)
+        fH, fW = depth.shape[-2:]
+        out = depth.unsqueeze(1) * feat.unsqueeze(2)
+        return out.view(B, N, self.C, self.D, fH, fW).permute(0, 1, 3, 4, 5, 2), est, gt, counts
+
+    def forward(self, *args, **kwargs):
+        x, depth_loss = super().forward(*args, **kwargs)
+        return self.downsample(x), depth_loss

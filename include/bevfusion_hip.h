@@ -109,6 +109,53 @@ int bfhip_hard_voxelize(const float *points, int n, int f, float *voxels, int32_
                         void *workspace, size_t workspace_bytes, int32_t *voxel_num_dev,
                         void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * camera frustum -> BEV plan  (replaces BaseViewTransform.get_geometry + bev_pool_aux,
+ *   BF/depth_lss.py:68-112,118-176, and the interval construction of
+ *   BF/ops/bev_pool/bev_pool.py:48-54; sync-free: all counts stay on the device)
+ *   frustum        f32[D*HW, 3]  pixel-depth grid (depth_lss.py:53-66)
+ *   per camera (B*N rows): post_trans f32[3], post_rots_inv f32[9], combine f32[9]
+ *                          (= camera2lidar_rots @ intrins_inverse, depth_lss.py:93), c2l_trans f32[3]
+ *   per sample (B rows)  : extra_rots f32[9], extra_trans f32[3]   (identity / 0 when absent)
+ *   origin_host = bx - dx/2, dx_host, nx_host = (nx[0], nx[1], nx[2])   (depth_lss.py:14-18)
+ * geometry is evaluated per point in fp32 with the fixed association ((m0*p0+m1*p1)+m2*p2), no
+ * fma; cell = trunc((p - origin)/dx); kept = inside the grid; rank = x*(nx1*nx2*B) + y*(nx2*B)
+ * + z*B + b; kept points are STABLY sorted by rank (the reference's argsort is unstable).
+ * outputs (N' = B*N*D*HW rows where sized by points; mmax rows where sized by intervals):
+ *   sorted_pd        u32[N']  (pixel_index << 8 | depth_bin) of the k-th sorted kept point
+ *   starts, lengths  i32[mmax], cell_of_interval i32[mmax] (offset of the cell in out[b][z][x][y])
+ *   counts_dev       i32[2] = {n_kept, n_intervals}
+ *   optional (may be NULL): cell_of_point i32[N'] (out cell of every frustum point or -1; needed by
+ *   lift_splat_bwd), geom_sorted i32[N',4] (x,y,z,b), ranks_sorted i64[N'], kept u8[N'],
+ *   geom_xyz f32[N',3] (the materialised get_geometry output, for parity tests)
+ * --------------------------------------------------------------------------------------- */
+size_t bfhip_bev_plan_workspace_bytes(long long nprime, long long ncells_times_b);
+int bfhip_bev_plan(const float *frustum, const float *post_trans, const float *post_rots_inv,
+                   const float *combine, const float *c2l_trans, const float *extra_rots,
+                   const float *extra_trans, int B, int N, int D, int HW,
+                   const float *origin_host, const float *dx_host, const int32_t *nx_host,
+                   uint32_t *sorted_pd, int32_t *starts, int32_t *lengths,
+                   int32_t *cell_of_interval, int32_t *counts_dev, int32_t *cell_of_point,
+                   int32_t *geom_sorted, int64_t *ranks_sorted, uint8_t *kept, float *geom_xyz,
+                   int mmax, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * fused lift-splat  (replaces the outer product BF/depth_lss.py:723-725, the two gathers
+ *   x[kept][indices] :190-194 and the bev_pool op, without materialising x[N', C])
+ *   depth f32[P, depth_pitch] (softmax over D bins, pixel-major), feat f32[P, feat_pitch]
+ *   (C channels, pixel-major), P = B*N*HW pixels; plan arrays from bfhip_bev_plan.
+ *   out f32[out_cells, C] with out_cells = B*nx2*nx0*nx1, zero-filled by the call.
+ * bwd: d_depth[p,d] = <out_grad[cell(p,d)], feat[p]>, d_feat[p] = sum_d depth[p,d]*out_grad[cell(p,d)]
+ * --------------------------------------------------------------------------------------- */
+int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const float *feat, int feat_pitch,
+                         const uint32_t *sorted_pd, const int32_t *starts, const int32_t *lengths,
+                         const int32_t *cell_of_interval, const int32_t *counts_dev, int mmax, int C,
+                         long long out_cells, float *out, void *stream);
+int bfhip_lift_splat_bwd(const float *out_grad, const float *depth, int depth_pitch,
+                         const float *feat, int feat_pitch, const int32_t *cell_of_point,
+                         int num_cams, int D, int HW, int C, float *d_depth, int d_depth_pitch,
+                         float *d_feat, int d_feat_pitch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

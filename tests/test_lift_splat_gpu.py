@@ -1,0 +1,209 @@
+"""GPU parity: csrc/lift_splat.hip (bev plan + fused lift-splat) vs the oracle and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+import bevfusion_amd  # noqa: F401
+import oracle
+from bevfusion_amd import synthetic
+from bevfusion_amd.depth_lss import LSSTransform, DepthLSSTransform, lift_splat
+
+from util import rel_err, sha
+
+pytestmark = pytest.mark.gpu
+NUSC = synthetic.NUSC
+
+TINY = dict(in_channels=16, out_channels=8, image_size=(64, 176), feature_size=(8, 22),
+            xbound=[-54.0, 54.0, 1.2], ybound=[-54.0, 54.0, 1.2], zbound=[-10.0, 10.0, 20.0], dbound=[1.0, 61.0, 3.0])
+FULL = dict(in_channels=256, out_channels=80, image_size=NUSC["image_size"], feature_size=NUSC["feature_size"],
+            xbound=NUSC["xbound"], ybound=NUSC["ybound"], zbound=NUSC["zbound"], dbound=NUSC["dbound"])
+
+
+def _calib(vt, rig, dev):
+    t = {k: torch.from_numpy(v).to(dev) for k, v in rig.items()}
+    return vt._calibration(t["camera_intrinsics"], t["camera2lidar"], t["img_aug_matrix"], t["lidar_aug_matrix"])
+
+
+def _oracle_plan(vt, cal, B):
+    """The same plan on the CPU oracle, from the same host-prepared matrices."""
+    c = {k: v.cpu() for k, v in cal.items()}
+    combine = cal["camera2lidar_rots"].matmul(cal["intrins_inverse"]).cpu().numpy()  # same device matmul as the product
+    geom = oracle.frustum_geometry(vt.frustum.detach().cpu().numpy(), c["post_trans"].numpy(),
+                                   c["post_rots_inverse"].numpy(), combine, c["camera2lidar_trans"].numpy(),
+                                   c["extra_rots"].numpy(), c["extra_trans"].numpy())
+    gf, kept, ranks, idx = oracle.bev_pool_aux(geom, B, np.array(vt._origin_host, np.float32),
+                                               np.array(vt._dx_host, np.float32), np.array(vt._nx_host, np.int32))
+    return geom, gf, kept, ranks, idx
+
+
+def _tiny_rig(golden_lss):
+    return {k[len("tiny_rig_"):]: golden_lss[k] for k in golden_lss.files if k.startswith("tiny_rig_")}
+
+
+def test_plan_tiny_vs_oracle_and_reference(dev, golden_lss):
+    vt = LSSTransform(**TINY).to(dev)
+    rig = _tiny_rig(golden_lss)
+    B = 2
+    cal = _calib(vt, rig, dev)
+    plan = vt.make_plan(**cal, with_reference_outputs=True, with_geometry=True)
+    geom, gf, kept, ranks, idx = _oracle_plan(vt, cal, B)
+    nk, m = [int(v) for v in plan.counts.cpu()]
+    # geometry: bit-identical to the oracle's fixed-order evaluation; ~1 ulp from the reference's torch evaluation
+    assert np.array_equal(plan.geom_xyz.cpu().numpy().reshape(geom.shape), geom)
+    assert np.abs(plan.geom_xyz.cpu().numpy().reshape(geom.shape) - golden_lss["tiny_geom"]).max() < 5e-5
+    # cells / kept / ranks: bit-identical to the oracle
+    assert nk == kept.sum()
+    assert np.array_equal(plan.kept.cpu().numpy().astype(bool), kept)
+    assert np.array_equal(plan.ranks_sorted[:nk].cpu().numpy(), ranks)
+    assert np.array_equal(plan.geom_sorted[:nk].cpu().numpy(), gf)
+    # stable order: the k-th sorted row is frustum point src[k]
+    pd = plan.sorted_pd[:nk].cpu().numpy().view(np.uint32)
+    D, HW = plan.D, plan.HW
+    pix, dd = pd >> 8, pd & 255
+    src = (pix // HW) * (D * HW) + dd * HW + (pix % HW)
+    assert np.array_equal(src, np.flatnonzero(kept)[idx])
+    starts, lengths = oracle.intervals_from_ranks(ranks)
+    assert m == len(starts)
+    assert np.array_equal(plan.starts[:m].cpu().numpy(), starts)
+    assert np.array_equal(plan.lengths[:m].cpu().numpy(), lengths)
+    assert not plan.lengths[m:].any()
+    g0 = gf[starts]
+    nx = vt._nx_host
+    assert np.array_equal(plan.cell_of_interval[:m].cpu().numpy(), ((g0[:, 3] * nx[2] + g0[:, 2]) * nx[0] + g0[:, 0]) * nx[1] + g0[:, 1])
+    # against the REFERENCE's bev_pool_aux outputs (its own torch geometry): identical here
+    assert np.array_equal(plan.kept.cpu().numpy().astype(bool), golden_lss["tiny_kept"])
+    assert np.array_equal(plan.ranks_sorted[:nk].cpu().numpy(), golden_lss["tiny_ranks"])
+    assert np.array_equal(plan.geom_sorted[:nk].cpu().numpy(), golden_lss["tiny_geom_feats"])
+
+
+def test_plan_full_size_counts_vs_reference(dev, golden_lss):
+    vt = LSSTransform(**FULL).to(dev)
+    cal = _calib(vt, synthetic.camera_rig(batch=1), dev)
+    plan = vt.make_plan(**cal, with_reference_outputs=True)
+    nk, m = [int(v) for v in plan.counts.cpu()]
+    nprime, ref_kept, ref_m, ref_maxlen, _ = [int(v) for v in golden_lss["full_counts"]]
+    assert plan.nprime == nprime
+    assert abs(nk - ref_kept) <= 20 and abs(m - ref_m) <= 20      # boundary-rounding flips only
+    assert abs(int(plan.lengths.max()) - ref_maxlen) <= 4
+    geom, gf, kept, ranks, idx = _oracle_plan(vt, cal, 1)
+    assert nk == kept.sum()
+    assert np.array_equal(plan.kept.cpu().numpy().astype(bool), kept)
+    assert np.array_equal(plan.ranks_sorted[:nk].cpu().numpy(), ranks)
+    rk = plan.ranks_sorted[:nk]
+    assert bool((rk[1:] >= rk[:-1]).all())                          # sortedness
+    assert int(plan.lengths[:m].sum()) == nk                        # intervals partition the kept rows
+
+
+def _random_depth_feat(dev, P, D, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    depth = torch.softmax(torch.randn(P, D, generator=g), 1).to(dev)
+    feat = torch.randn(P, C, generator=g).to(dev)
+    return depth, feat
+
+
+def _to_ref_layout(depth, feat, BN, fH, fW):
+    D, C = depth.shape[1], feat.shape[1]
+    d = depth.view(BN, fH, fW, D).permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    f = feat.view(BN, fH, fW, C).permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    return d, f
+
+
+@pytest.mark.parametrize("train_aug", [False, True])
+def test_lift_splat_fwd_bwd_vs_oracle(dev, train_aug):
+    cfg = dict(TINY, out_channels=80)
+    vt = LSSTransform(**cfg).to(dev)
+    B = 2
+    rig = synthetic.camera_rig(batch=B, seed=3, train_aug=train_aug)
+    rig["img_aug_matrix"][..., 0, 0] = rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3], rig["img_aug_matrix"][..., 1, 3] = -8.0, -44.0
+    cal = _calib(vt, rig, dev)
+    plan = vt.make_plan(**cal)
+    fH, fW = cfg["feature_size"]
+    BN, D, C = B * 6, vt.D, 80
+    depth, feat = _random_depth_feat(dev, BN * fH * fW, D, C, seed=1)
+    depth.requires_grad_(True)
+    feat.requires_grad_(True)
+    out = lift_splat(depth, feat, plan)
+    geom, gf, kept, ranks, idx = _oracle_plan(vt, cal, B)
+    starts, lengths = oracle.intervals_from_ranks(ranks)
+    src = np.flatnonzero(kept)[idx].astype(np.int32)
+    d_ref, f_ref = _to_ref_layout(depth.detach(), feat.detach(), BN, fH, fW)
+    nx = vt._nx_host
+    want = oracle.lift_splat_fwd(d_ref, f_ref, src, gf, starts, lengths, B, nx[2], nx[0], nx[1])
+    assert np.array_equal(out.detach().cpu().numpy(), want)          # same order, same rounding: bit-exact
+    og = torch.randn(out.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    out.backward(og)
+    dd, df = oracle.lift_splat_bwd(og.cpu().numpy(), d_ref, f_ref, src, gf, starts, lengths)
+    dd_pm = np.transpose(dd, (0, 2, 3, 1)).reshape(-1, D)
+    df_pm = np.transpose(df, (0, 2, 3, 1)).reshape(-1, C)
+    assert rel_err(depth.grad.cpu().numpy(), dd_pm) < 1e-5            # tree vs sequential channel sum
+    assert rel_err(feat.grad.cpu().numpy(), df_pm) < 1e-5
+
+
+def test_module_fused_equals_op_boundary_path(dev, golden_lss):
+    """BaseViewTransform.bev_pool(x, geom) (the reference's materialised path through the bev_pool op)
+    reproduces the reference's python-glue golden, and the fused lift-splat equals it."""
+    vt = LSSTransform(**TINY).to(dev).eval()
+    rig = _tiny_rig(golden_lss)
+    B, N = 2, 6
+    D, (fH, fW), C = vt.D, TINY["feature_size"], TINY["out_channels"]
+    x = torch.randn(B, N, D, fH, fW, C, generator=torch.Generator().manual_seed(123))
+    assert sha(x.numpy()) == str(golden_lss["tiny_x_sha"])
+    geom = torch.from_numpy(golden_lss["tiny_geom"]).to(dev)
+    bev = vt.bev_pool(x.to(dev), geom)
+    assert bev.shape == golden_lss["tiny_bev"].shape
+    assert rel_err(bev.cpu().numpy(), golden_lss["tiny_bev"]) < 1e-6
+    # fused: random depth/feat through both paths
+    cal = _calib(vt, rig, dev)
+    plan = vt.make_plan(**cal)
+    g = torch.Generator().manual_seed(7)
+    depth = torch.softmax(torch.randn(B * N, D, fH, fW, generator=g), 1).to(dev)
+    feat = torch.randn(B * N, C, fH, fW, generator=g).to(dev)
+    fused = vt.lift_splat_bev(depth, feat, plan)
+    xm = (depth.unsqueeze(1) * feat.unsqueeze(2)).view(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2)
+    mat = vt.bev_pool(xm, vt.get_geometry(**{k: v for k, v in cal.items()}))
+    assert torch.equal(fused, mat)
+
+
+def test_depth_lss_transform_forward_backward(dev):
+    """DepthLSSTransform end to end at reduced size: runs, shapes as the reference documents, gradients flow."""
+    cfg = dict(TINY, in_channels=32, out_channels=16, downsample=2)
+    vt = DepthLSSTransform(**cfg).to(dev).train()
+    B, N = 2, 6
+    rig = synthetic.camera_rig(batch=B, seed=1, train_aug=True)
+    rig["img_aug_matrix"][..., 0, 0] = rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3], rig["img_aug_matrix"][..., 1, 3] = -8.0, -44.0
+    t = {k: torch.from_numpy(v).to(dev) for k, v in rig.items()}
+    img = torch.randn(B, N, 32, 8, 22, device=dev, requires_grad=True)
+    pts = [torch.from_numpy(synthetic.lidar_sweep(5000, seed=s)).to(dev) for s in (1, 2)]
+    keep = [p.clone() for p in pts]
+    x, depth_loss = vt(img, pts, t["lidar2image"], t["camera_intrinsics"], t["camera2lidar"], t["img_aug_matrix"],
+                       t["lidar_aug_matrix"], None)
+    assert x.shape == (B, 16, 45, 45)
+    assert all(torch.equal(a, b) for a, b in zip(pts, keep))  # inputs not mutated
+    (x.sum() + depth_loss).backward()
+    assert img.grad is not None and torch.isfinite(img.grad).all() and img.grad.abs().sum() > 0
+    assert vt.depthnet[0].weight.grad.abs().sum() > 0
+
+
+def test_full_size_properties(dev):
+    """BASELINE-size fused op (1 993 728 frustum points, C=80, 360x360): linearity in feat, mass
+    conservation, and equality with the op-boundary bev_pool on the materialised tensor."""
+    from bevfusion_amd.ops import bev_pool_ext
+    vt = LSSTransform(**FULL).to(dev)
+    cal = _calib(vt, synthetic.camera_rig(batch=1), dev)
+    plan = vt.make_plan(**cal, with_reference_outputs=True)
+    nk, m = [int(v) for v in plan.counts.cpu()]
+    P, D, C = 6 * 32 * 88, vt.D, 80
+    depth, f1 = _random_depth_feat(dev, P, D, C, seed=5)
+    _, f2 = _random_depth_feat(dev, P, D, C, seed=6)
+    o1, o2, o12 = lift_splat(depth, f1, plan), lift_splat(depth, f2, plan), lift_splat(depth, f1 + f2, plan)
+    assert rel_err((o1 + o2).cpu().numpy(), o12.cpu().numpy()) < 1e-5
+    # materialised path through the op: x rows in sorted order
+    pd = plan.sorted_pd[:nk].long() & 0xFFFFFFFF
+    pix, dd = pd >> 8, pd & 255
+    x = depth[pix, dd].unsqueeze(1) * f1[pix]
+    ref = bev_pool_ext.bev_pool_forward(x, plan.geom_sorted[:nk].contiguous(), plan.lengths[:m].contiguous(),
+                                        plan.starts[:m].contiguous(), 1, 1, 360, 360)
+    assert torch.equal(o1, ref)
+    assert torch.allclose(o1.double().sum((0, 1, 2, 3)), x.double().sum(0), rtol=1e-6, atol=1e-3)
