@@ -34,6 +34,19 @@ SIGNATURES = {
                                        _c_vp, _c_vp]),
     "bfhip_lift_splat_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 4 +
                              [_c_vp, _c_int, _c_vp, _c_int, _c_vp]),
+    "bfhip_conv_out_shape": (_c_int, [_c_vp] * 6),
+    "bfhip_rulebook_subm_workspace_bytes": (_c_sz, [_c_int]),
+    "bfhip_rulebook_subm": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_rulebook_sparse_workspace_bytes": (_c_sz, [_c_int] + [_c_vp] * 5),
+    "bfhip_rulebook_sparse_count": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 5 + [_c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_rulebook_sparse_fill": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
+                                   [_c_vp, _c_sz, _c_vp]),
+    "bfhip_spconv_workspace_bytes": (_c_sz, [_c_int] * 3),
+    "bfhip_spconv_gemm": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_spconv_wgrad_workspace_bytes": (_c_sz, [_c_int] * 4),
+    "bfhip_spconv_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_sparse_to_bev": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
+    "bfhip_bev_to_sparse": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
 }
 
 _lib = None
@@ -70,6 +83,10 @@ def ptr(t):
 
 def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def host_i32(values):
+    return (ctypes.c_int32 * len(values))(*[int(v) for v in values])
 
 
 def host_f32(values):

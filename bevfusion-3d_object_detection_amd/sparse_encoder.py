@@ -1,0 +1,148 @@
+"""Host mirror of the LiDAR middle encoder: `BEVFusionSparseEncoder` (BF/sparse_encoder.py:12-156),
+its layer factory `make_encoder_layers` (mmdet3d/models/middle_encoders/sparse_encoder.py:165-241),
+`SparseBasicBlock` and `make_sparse_convmodule` (mmdet3d/models/layers/sparse_block.py:94-224).
+Conv arithmetic: csrc/spconv.hip via spconv.py; BatchNorm1d / ReLU on the [N, C] feature matrix are torch.
+"""
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from .registry import MODELS
+from .spconv import (SparseConv3d, SparseConvTensor, SparseModule, SparseSequential, SubMConv3d,  # noqa: F401
+                     replace_feature)
+
+_CONV_TYPES = {"SubMConv3d": SubMConv3d, "SparseConv3d": SparseConv3d}
+
+
+def build_norm_1d(norm_cfg, channels):
+    cfg = dict(norm_cfg or dict(type="BN1d"))
+    typ = cfg.pop("type")
+    assert typ in ("BN1d", "BN"), typ
+    cfg.pop("requires_grad", None)
+    return nn.BatchNorm1d(channels, **cfg)
+
+
+def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0,
+                           conv_type="SubMConv3d", norm_cfg=None, order=("conv", "norm", "act"), **kwargs):
+    """conv (bias=False) / BN1d / ReLU in the requested order, as a SparseSequential."""
+    assert isinstance(order, tuple) and len(order) <= 3
+    assert set(order) | {"conv", "norm", "act"} == {"conv", "norm", "act"}
+    layers = []
+    for layer in order:
+        if layer == "conv":
+            layers.append(_CONV_TYPES[conv_type](in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                                 bias=False, indice_key=indice_key))
+        elif layer == "norm":
+            layers.append(build_norm_1d(norm_cfg, out_channels))
+        elif layer == "act":
+            layers.append(nn.ReLU(inplace=True))
+    return SparseSequential(*layers)
+
+
+class SparseBasicBlock(SparseModule):
+    """Two 3x3x3 SubM convs + BN + ReLU with an identity shortcut
+    (mmdet3d/models/layers/sparse_block.py:94-154; attribute names conv1/norm1/conv2/norm2 as mmdet's BasicBlock)."""
+
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, indice_key=None, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        conv_cfg = dict(conv_cfg or dict(type="SubMConv3d"))
+        conv_cfg.setdefault("indice_key", indice_key)
+        conv_cls = _CONV_TYPES[conv_cfg.pop("type")]
+        self.conv1 = conv_cls(inplanes, planes, 3, stride=stride, padding=1, bias=False, **conv_cfg)
+        self.norm1 = build_norm_1d(norm_cfg, planes)
+        self.conv2 = conv_cls(planes, planes, 3, padding=1, bias=False, **conv_cfg)
+        self.norm2 = build_norm_1d(norm_cfg, planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x.features
+        assert x.features.dim() == 2
+        out = self.conv1(x)
+        out = replace_feature(out, self.relu(self.norm1(out.features)))
+        out = self.conv2(out)
+        out = replace_feature(out, self.norm2(out.features))
+        if self.downsample is not None:
+            identity = self.downsample(x).features
+        return replace_feature(out, self.relu(out.features + identity))
+
+
+@MODELS.register_module()
+class BEVFusionSparseEncoder(nn.Module):
+    """Sparse encoder of BEVFusion; spatial order (X, Y, Z) as produced by this fork's voxelization.
+
+    forward(voxel_features [N,C], coors int[N,4]=(b,x,y,z), batch_size) -> [B, C_out*Z_out, X_out, Y_out]
+    """
+
+    def __init__(self, in_channels, sparse_shape, order=("conv", "norm", "act"),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type="conv_module",
+                 return_middle_feats=False):
+        super().__init__()
+        assert block_type in ["conv_module", "basicblock"]
+        assert isinstance(order, tuple) and len(order) == 3 and set(order) == {"conv", "norm", "act"}
+        self.sparse_shape = sparse_shape
+        self.in_channels = in_channels
+        self.order = order
+        self.base_channels = base_channels
+        self.output_channels = output_channels
+        self.encoder_channels = encoder_channels
+        self.encoder_paddings = encoder_paddings
+        self.stage_num = len(encoder_channels)
+        self.fp16_enabled = False
+        self.return_middle_feats = return_middle_feats
+        first_order = ("conv",) if order[0] != "conv" else order  # pre-activation variant keeps a bare first conv
+        self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                 indice_key="subm1", conv_type="SubMConv3d", order=first_order)
+        encoder_out_channels = self.make_encoder_layers(make_sparse_convmodule, norm_cfg, base_channels,
+                                                        block_type=block_type)
+        self.conv_out = make_sparse_convmodule(encoder_out_channels, output_channels, kernel_size=(1, 1, 3),
+                                               stride=(1, 1, 2), norm_cfg=norm_cfg, padding=0,
+                                               indice_key="spconv_down2", conv_type="SparseConv3d")
+
+    def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type="conv_module",
+                            conv_cfg=dict(type="SubMConv3d")):
+        self.encoder_layers = SparseSequential()
+        out_channels = in_channels
+        for i, blocks in enumerate(self.encoder_channels):
+            blocks_list = []
+            for j, out_channels in enumerate(tuple(blocks)):
+                padding = tuple(self.encoder_paddings[i])[j]
+                last_of_stage = j == len(blocks) - 1 and i != len(self.encoder_channels) - 1
+                if i != 0 and j == 0 and block_type == "conv_module":
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                  padding=padding, indice_key=f"spconv{i + 1}",
+                                                  conv_type="SparseConv3d"))
+                elif block_type == "basicblock":
+                    if last_of_stage:
+                        blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                      padding=padding, indice_key=f"spconv{i + 1}",
+                                                      conv_type="SparseConv3d"))
+                    else:
+                        blocks_list.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg,
+                                                            conv_cfg=conv_cfg))
+                else:
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, padding=padding,
+                                                  indice_key=f"subm{i + 1}", conv_type="SubMConv3d"))
+                in_channels = out_channels
+            self.encoder_layers.add_module(f"encoder_layer{i + 1}", SparseSequential(*blocks_list))
+        return out_channels
+
+    def forward(self, voxel_features, coors, batch_size):
+        coors = coors.int()
+        x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        x = self.conv_input(x)
+        encode_features = []
+        for encoder_layer in self.encoder_layers:
+            x = encoder_layer(x)
+            encode_features.append(x)
+        out = self.conv_out(encode_features[-1])
+        # out.dense() -> [N, C, X, Y, Z] -> permute(0,1,4,2,3) -> view(N, C*Z, X, Y)   (BF/sparse_encoder.py:147-151)
+        spatial_features = out.to_bev()
+        if self.return_middle_feats:
+            return spatial_features, encode_features
+        return spatial_features

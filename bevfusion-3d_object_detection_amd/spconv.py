@@ -1,0 +1,361 @@
+"""Sparse convolution modules under the names the reference builds by registry
+('SubMConv3d', 'SparseConv3d'; mmdet3d/models/layers/spconv/overwrite_spconv/write_spconv2.py:13-39)
+and the container types it imports from spconv.pytorch (`SparseConvTensor`, `SparseModule`,
+`SparseSequential`; mmdet3d/models/layers/sparse_block.py:11-14, BF/sparse_encoder.py:133).
+
+The arithmetic runs in csrc/spconv.hip.  API surface kept from traveller59/spconv 2.x as the
+reference uses it: `SparseConvTensor(features, indices, spatial_shape, batch_size)` with
+`.features .indices .spatial_shape .batch_size .indice_dict .replace_feature() .dense()
+.find_indice_pair() .shadow_copy()`; convs take (in_channels, out_channels, kernel_size,
+stride=, padding=, dilation=, bias=, indice_key=); weight layout (out, k0, k1, k2, in).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+from .registry import MODELS
+
+
+def _triple(v):
+    return [int(v)] * 3 if isinstance(v, int) else [int(a) for a in v]
+
+
+_WS = {}
+
+
+def _workspace(device, nbytes, tag="ws"):
+    key = (device, tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+class IndiceData:
+    """Rulebook of one convolution (what spconv keeps in `indice_dict[indice_key]`)."""
+
+    def __init__(self, out_indices, pair_fwd, pair_bwd, n_pairs, is_subm, out_spatial_shape, ksize, stride, padding,
+                 dilation):
+        self.out_indices = out_indices      # i32[N_out, 4]
+        self.pair_fwd = pair_fwd            # i32[KV, N_out]
+        self.pair_bwd = pair_bwd            # i32[KV, N_in] (None for SubM: pair_fwd with flipped offsets)
+        self.n_pairs = n_pairs              # device i32[1]
+        self.is_subm = is_subm
+        self.out_spatial_shape = out_spatial_shape
+        self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+
+
+def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation):
+    N = indices.shape[0]
+    kv = ksize[0] * ksize[1] * ksize[2]
+    dev = indices.device
+    pair_fwd = torch.empty((kv, N), dtype=torch.int32, device=dev)
+    n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    ws = _workspace(dev, lib.bfhip_rulebook_subm_workspace_bytes(N), "rule")
+    with torch.cuda.device(dev):
+        rc = lib.bfhip_rulebook_subm(_lib.ptr(indices), N, batch_size, _lib.host_i32(spatial_shape), _lib.host_i32(ksize),
+                                     _lib.host_i32(dilation), _lib.ptr(pair_fwd), _lib.ptr(n_pairs), _lib.ptr(ws),
+                                     ws.numel(), _lib.stream_of(indices))
+    _lib.check(rc, "rulebook_subm")
+    return IndiceData(indices, pair_fwd, None, n_pairs, True, list(spatial_shape), ksize, [1, 1, 1], None, dilation)
+
+
+def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
+    """(in + 2p - d(k-1) - 1)//s + 1 (projects/SparseConvolution/sparse_conv.py:88-90)."""
+    return [(spatial_shape[i] + 2 * padding[i] - dilation[i] * (ksize[i] - 1) - 1) // stride[i] + 1 for i in range(3)]
+
+
+def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation):
+    N = indices.shape[0]
+    kv = ksize[0] * ksize[1] * ksize[2]
+    dev = indices.device
+    lib = _lib.load()
+    geo = [_lib.host_i32(spatial_shape), _lib.host_i32(ksize), _lib.host_i32(stride), _lib.host_i32(padding),
+           _lib.host_i32(dilation)]
+    nbytes = lib.bfhip_rulebook_sparse_workspace_bytes(batch_size, *geo)
+    if nbytes == 0:
+        raise RuntimeError("SparseConv3d: unsupported geometry")
+    ws = _workspace(dev, nbytes, "rule")
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    stream = _lib.stream_of(indices)
+    with torch.cuda.device(dev):
+        rc = lib.bfhip_rulebook_sparse_count(_lib.ptr(indices), N, batch_size, *geo, _lib.ptr(counts), _lib.ptr(ws),
+                                             ws.numel(), stream)
+        _lib.check(rc, "rulebook_sparse_count")
+        n_out = int(counts[0].item())  # the one host sync of a strided layer (spconv returns num_act_out too)
+        out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+        pair_fwd = torch.empty((kv, n_out), dtype=torch.int32, device=dev)
+        pair_bwd = torch.empty((kv, N), dtype=torch.int32, device=dev)
+        rc = lib.bfhip_rulebook_sparse_fill(_lib.ptr(indices), N, batch_size, *geo, n_out, _lib.ptr(out_indices),
+                                            _lib.ptr(pair_fwd), _lib.ptr(pair_bwd), _lib.ptr(counts), _lib.ptr(ws),
+                                            ws.numel(), stream)
+    _lib.check(rc, "rulebook_sparse_fill")
+    return IndiceData(out_indices, pair_fwd, pair_bwd, counts[1:], False,
+                      conv_out_shape(spatial_shape, ksize, stride, padding, dilation), ksize, stride, padding, dilation)
+
+
+def _gemm(inp, weight, pairs, n_rows, transpose, flip):
+    cout, cin = weight.shape[0], weight.shape[-1]
+    kv = pairs.shape[0]
+    out = torch.empty((n_rows, cin if transpose else cout), dtype=torch.float32, device=inp.device)
+    lib = _lib.load()
+    ws = _workspace(inp.device, lib.bfhip_spconv_workspace_bytes(kv, cin, cout), "gemm")
+    with torch.cuda.device(inp.device):
+        rc = lib.bfhip_spconv_gemm(_lib.ptr(inp), _lib.ptr(weight), _lib.ptr(pairs), pairs.shape[1], kv, n_rows, cin,
+                                   cout, 1 if transpose else 0, 1 if flip else 0, _lib.ptr(out), _lib.ptr(ws),
+                                   ws.numel(), _lib.stream_of(inp))
+    _lib.check(rc, "spconv_gemm")
+    return out
+
+
+class _SparseConvFunction(torch.autograd.Function):
+    """features [N_in, Cin], weight (Cout,k0,k1,k2,Cin) -> [N_out, Cout]."""
+
+    @staticmethod
+    def forward(ctx, features, weight, data, n_in):
+        features = features.contiguous().float()
+        w = weight.contiguous().float()
+        out = _gemm(features, w, data.pair_fwd, data.pair_fwd.shape[1], False, False)
+        ctx.save_for_backward(features, w)
+        ctx.data = data
+        ctx.n_in = n_in
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, w = ctx.saved_tensors
+        data = ctx.data
+        grad_out = grad_out.contiguous().float()
+        d_feat = d_w = None
+        if ctx.needs_input_grad[0]:
+            if data.is_subm:
+                d_feat = _gemm(grad_out, w, data.pair_fwd, ctx.n_in, True, True)
+            else:
+                d_feat = _gemm(grad_out, w, data.pair_bwd, ctx.n_in, True, False)
+        if ctx.needs_input_grad[1]:
+            cout, cin = w.shape[0], w.shape[-1]
+            kv = data.pair_fwd.shape[0]
+            n_out = data.pair_fwd.shape[1]
+            d_w = torch.empty_like(w)
+            lib = _lib.load()
+            ws = _workspace(w.device, lib.bfhip_spconv_wgrad_workspace_bytes(kv, cin, cout, n_out), "wgrad")
+            with torch.cuda.device(w.device):
+                rc = lib.bfhip_spconv_wgrad(_lib.ptr(features), _lib.ptr(grad_out), _lib.ptr(data.pair_fwd), n_out, kv,
+                                            n_out, cin, cout, _lib.ptr(d_w), _lib.ptr(ws), ws.numel(),
+                                            _lib.stream_of(w))
+            _lib.check(rc, "spconv_wgrad")
+        return d_feat, d_w, None, None
+
+
+class _ToBevFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, B, X, Y, Z):
+        features = features.contiguous().float()
+        N, C = features.shape
+        out = torch.empty((B, C * Z, X, Y), dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device):
+            rc = _lib.load().bfhip_sparse_to_bev(_lib.ptr(features), _lib.ptr(indices), N, C, B, X, Y, Z, _lib.ptr(out),
+                                                 _lib.stream_of(features))
+        _lib.check(rc, "sparse_to_bev")
+        ctx.save_for_backward(indices)
+        ctx.shape = (N, C, B, X, Y, Z)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (indices,) = ctx.saved_tensors
+        N, C, B, X, Y, Z = ctx.shape
+        grad_out = grad_out.contiguous()
+        g = torch.empty((N, C), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            rc = _lib.load().bfhip_bev_to_sparse(_lib.ptr(grad_out), _lib.ptr(indices), N, C, B, X, Y, Z, _lib.ptr(g),
+                                                 _lib.stream_of(grad_out))
+        _lib.check(rc, "bev_to_sparse")
+        return g, None, None, None, None, None
+
+
+class SparseConvTensor:
+    """features f32[N,C], indices i32[N,4] = (batch, x, y, z) in this fork's axis order
+    (BF/sparse_encoder.py:133), spatial_shape [X,Y,Z], batch_size."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None, indice_dict=None,
+                 benchmark=False):
+        assert features.dim() == 2 and indices.dim() == 2 and indices.shape[1] == 4
+        assert indices.dtype == torch.int32, "indices must be int32"
+        self.features = features
+        self.indices = indices.contiguous()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = indice_dict if indice_dict is not None else {}
+        self.benchmark = benchmark
+        self._auto_rulebooks = {}  # SubM rulebooks keyed by (ksize, dilation); valid while indices are unchanged
+
+    def replace_feature(self, feature):
+        new = self.shadow_copy()
+        new.features = feature
+        return new
+
+    def shadow_copy(self):
+        t = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size,
+                             indice_dict=self.indice_dict, benchmark=self.benchmark)
+        t._auto_rulebooks = self._auto_rulebooks
+        return t
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    @property
+    def spatial_size(self):
+        return math.prod(self.spatial_shape)
+
+    def dense(self, channels_first=True):
+        """[B, C, X, Y, Z] (channels_first) like spconv's .dense()."""
+        bev = self.to_bev()  # [B, C*Z, X, Y]
+        B, X, Y, Z = self.batch_size, *self.spatial_shape
+        C = self.features.shape[1]
+        out = bev.view(B, C, Z, X, Y).permute(0, 1, 3, 4, 2)
+        return out if channels_first else out.permute(0, 2, 3, 4, 1)
+
+    def to_bev(self):
+        """dense() + permute(0,1,4,2,3) + view(B, C*Z, X, Y) in one kernel (BF/sparse_encoder.py:147-151)."""
+        X, Y, Z = self.spatial_shape
+        return _ToBevFunction.apply(self.features, self.indices, self.batch_size, X, Y, Z)
+
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that take and return a SparseConvTensor."""
+
+
+def is_spconv_module(m):
+    return isinstance(m, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """Sequential that applies plain nn modules to `.features` (as spconv's SparseSequential does)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for k, m in args[0].items():
+                self.add_module(k, m)
+        else:
+            for i, m in enumerate(args):
+                self.add_module(str(i), m)
+        for k, m in kwargs.items():
+            self.add_module(k, m)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        self.add_module(name if name is not None else str(len(self._modules)), module)
+
+    def forward(self, input):
+        for module in self._modules.values():
+            if is_spconv_module(module):
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input = input.replace_feature(module(input.features))
+            else:
+                input = module(input)
+        return input
+
+
+class SparseConvolution(SparseModule):
+    """Common base of SubMConv3d / SparseConv3d (spconv.pytorch.conv.SparseConvolution)."""
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 algo=None, fp32_accum=None, name=None):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not inverse, "only 3-D forward convs are implemented"
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.dilation = _triple(dilation)
+        self.subm = subm
+        self.indice_key = indice_key
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        # (out, k0, k1, k2, in): the on-disk layout of spconv 2.x checkpoints (write_spconv2.py:50-51)
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # spconv: kaiming_uniform_(a=sqrt(5)) with fan_in = in_channels * kernel volume
+        fan_in = self.in_channels * math.prod(self.kernel_size)
+        bound = math.sqrt(6.0 / ((1 + 5.0) * fan_in))
+        nn.init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            b = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -b, b)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, subm={self.subm}, indice_key={self.indice_key}")
+
+    def _rulebook(self, input):
+        data = input.find_indice_pair(self.indice_key)
+        if data is not None:
+            return data
+        if self.subm:
+            auto_key = (tuple(self.kernel_size), tuple(self.dilation))
+            data = input._auto_rulebooks.get(auto_key)
+            if data is None:
+                data = build_subm_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size,
+                                           self.dilation)
+                input._auto_rulebooks[auto_key] = data
+        else:
+            data = build_sparse_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size,
+                                         self.stride, self.padding, self.dilation)
+        if self.indice_key is not None:
+            input.indice_dict[self.indice_key] = data
+        return data
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        assert input.features.shape[1] == self.in_channels, "channel size mismatch"
+        _lib.require_cuda(input.features, "features")
+        data = self._rulebook(input)
+        n_in = input.features.shape[0]
+        out_features = _SparseConvFunction.apply(input.features, self.weight, data, n_in)
+        if self.bias is not None:
+            out_features = out_features + self.bias
+        if self.subm:
+            return input.replace_feature(out_features)
+        out = SparseConvTensor(out_features, data.out_indices, data.out_spatial_shape, input.batch_size,
+                               indice_dict=input.indice_dict, benchmark=input.benchmark)
+        return out
+
+
+@MODELS.register_module()
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+@MODELS.register_module()
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, False,
+                         indice_key=indice_key)
+
+
+def replace_feature(out, new_features):
+    """mmdet3d/models/layers/sparse_block.py:17-24"""
+    return out.replace_feature(new_features)

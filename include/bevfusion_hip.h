@@ -156,6 +156,57 @@ int bfhip_lift_splat_bwd(const float *out_grad, const float *depth, int depth_pi
                          int num_cams, int D, int HW, int C, float *d_depth, int d_depth_pitch,
                          float *d_feat, int d_feat_pitch, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * sparse 3-D convolution  (replaces what the reference delegates to spconv 2.x:
+ *   SpconvOps.get_indice_pairs_implicit_gemm, projects/SparseConvolution/sparse_functional.py:118-137;
+ *   ConvGemmOps.implicit_gemm :287-314; SparseConvTensor.dense(), BF/sparse_encoder.py:147)
+ *   indices i32[N,4] = (b, x, y, z), 16-byte aligned; shapes/ksize/stride/padding/dilation are host int[3]
+ *   pair table i32[KV, ld]: pair[k*ld + out_row] = input row or -1; offset k = (i*k1 + j)*k2 + l
+ *   weights f32 (Cout, k0, k1, k2, Cin) (mmdet3d/models/layers/spconv/overwrite_spconv/write_spconv2.py:50-51)
+ * SubM    : out rows = in rows; pad = dil*(k//2).
+ * strided : out shape (in + 2p - d(k-1) - 1)//s + 1 (projects/SparseConvolution/sparse_conv.py:88-90);
+ *           output rows in ASCENDING LINEAR ORDER ((b*X+x)*Y+y)*Z+z (canonical; spconv's is hash order).
+ *           Two phases because N_out must reach the host: _count writes counts_dev[0] = N_out;
+ *           _fill (same workspace, untouched in between) writes out_indices i32[n_out,4],
+ *           pair_fwd i32[KV,n_out], pair_bwd i32[KV,N] and counts_dev[1] = number of pairs.
+ * gemm    : out[n_rows, Ndim] = sum_k M_k . in[pairs[k][row]];  transpose=0 forward (M_k = W[:,k,:]^T),
+ *           transpose=1 dgrad (M_k = W[:,k',:], k' = KV-1-k when flip else k; flip=1 lets a SubM layer
+ *           reuse pair_fwd as its backward table).  Exact-fp32 MFMA, deterministic, no atomics.
+ * wgrad   : dW (Cout,KV,Cin) = sum_n dout[n] (x) in[pairs[k][n]], fixed-order reduction.
+ * sparse_to_bev: out f32[B, C*Z, X, Y] (zero-filled here) <- feats[n][c] at (b, c*Z+z, x, y);
+ * bev_to_sparse: its gather (backward).
+ * --------------------------------------------------------------------------------------- */
+int bfhip_conv_out_shape(const int *in_shape, const int *ksize, const int *stride,
+                         const int *padding, const int *dilation, int *out_shape);
+size_t bfhip_rulebook_subm_workspace_bytes(int N);
+int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const int *in_shape, const int *ksize,
+                        const int *dilation, int32_t *pair_fwd, int32_t *n_pairs_dev,
+                        void *workspace, size_t workspace_bytes, void *stream);
+size_t bfhip_rulebook_sparse_workspace_bytes(int B, const int *in_shape, const int *ksize,
+                                             const int *stride, const int *padding,
+                                             const int *dilation);
+int bfhip_rulebook_sparse_count(const int32_t *indices, int N, int B, const int *in_shape,
+                                const int *ksize, const int *stride, const int *padding,
+                                const int *dilation, int32_t *counts_dev, void *workspace,
+                                size_t workspace_bytes, void *stream);
+int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *in_shape,
+                               const int *ksize, const int *stride, const int *padding,
+                               const int *dilation, int n_out, int32_t *out_indices,
+                               int32_t *pair_fwd, int32_t *pair_bwd, int32_t *counts_dev,
+                               void *workspace, size_t workspace_bytes, void *stream);
+size_t bfhip_spconv_workspace_bytes(int KV, int Cin, int Cout);
+int bfhip_spconv_gemm(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
+                      int n_rows, int Cin, int Cout, int transpose, int flip, float *out,
+                      void *workspace, size_t workspace_bytes, void *stream);
+size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout, int n_rows);
+int bfhip_spconv_wgrad(const float *in, const float *dout, const int32_t *pairs, int ld, int KV,
+                       int n_rows, int Cin, int Cout, float *dW, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int bfhip_sparse_to_bev(const float *feats, const int32_t *indices, int N, int C, int B, int X,
+                        int Y, int Z, float *out, void *stream);
+int bfhip_bev_to_sparse(const float *grad_out, const int32_t *indices, int N, int C, int B, int X,
+                        int Y, int Z, float *grad_feats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
