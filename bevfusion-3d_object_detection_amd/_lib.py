@@ -47,6 +47,11 @@ SIGNATURES = {
     "bfhip_spconv_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_sparse_to_bev": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "bfhip_bev_to_sparse": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
+    "bfhip_dynamic_scatter_workspace_bytes": (_c_sz, [_c_int]),
+    "bfhip_dynamic_scatter_fwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_dynamic_scatter_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "bfhip_dynamic_scatter_bwd": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_voxel_mean": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
 }
 
 _lib = None

@@ -1,0 +1,196 @@
+"""Host mirror of the detector wiring, projects/BEVFusion/bevfusion/bevfusion.py (BEVFusion :23-399):
+voxelize loop + mean reduce, camera branch, LiDAR branch, fusion, BEV backbone/neck, head.
+
+Inputs follow the reference's `batch_inputs_dict` / metainfo contract (BF/bevfusion.py:300-322):
+  points: list[Tensor[Ni, F]], imgs: Tensor[B, N, 3, H, W], and per-sample 4x4 matrices
+  lidar2img, cam2img, cam2lidar, img_aug_matrix, lidar_aug_matrix.
+"""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from .ops import Voxelization
+from .ops.voxel import voxel_layer
+from .registry import MODELS
+from . import dense_modules, depth_lss, sparse_encoder  # noqa: F401  (register the module names)
+
+
+def voxel_mean(voxels, num_points):
+    """feats.sum(dim=1) / sizes (BF/bevfusion.py:251-253) as one kernel (bfhip_voxel_mean)."""
+    voxels = voxels.contiguous()
+    M, P, Fdim = voxels.shape
+    out = torch.empty((M, Fdim), dtype=torch.float32, device=voxels.device)
+    with torch.cuda.device(voxels.device):
+        rc = _lib.load().bfhip_voxel_mean(_lib.ptr(voxels), _lib.ptr(num_points.contiguous()), M, P, Fdim, _lib.ptr(out),
+                                          _lib.stream_of(voxels))
+    _lib.check(rc, "voxel_mean")
+    return out
+
+
+@MODELS.register_module()
+class BEVFusion(nn.Module):
+
+    def __init__(self, data_preprocessor: Optional[dict] = None, pts_voxel_encoder: Optional[dict] = None,
+                 pts_middle_encoder: Optional[dict] = None, fusion_layer: Optional[dict] = None,
+                 img_backbone: Optional[dict] = None, pts_backbone: Optional[dict] = None,
+                 view_transform: Optional[dict] = None, img_neck: Optional[dict] = None,
+                 pts_neck: Optional[dict] = None, bbox_head: Optional[dict] = None, **kwargs) -> None:
+        super().__init__()
+        voxelize_cfg = dict(data_preprocessor["voxelize_cfg"])
+        self.voxelize_reduce = voxelize_cfg.pop("voxelize_reduce")
+        if isinstance(voxelize_cfg.get("max_voxels"), list):
+            voxelize_cfg["max_voxels"] = tuple(voxelize_cfg["max_voxels"])
+        self.pts_voxel_layer = Voxelization(**voxelize_cfg)
+        # pts_voxel_encoder (HardSimpleVFE) is built but never called by the reference (:52, reduce is inline)
+        build = lambda cfg: MODELS.build(cfg) if cfg is not None else None
+        self.img_backbone = build(img_backbone)
+        self.img_neck = build(img_neck)
+        self.view_transform = build(view_transform)
+        self.pts_middle_encoder = build(pts_middle_encoder)
+        self.fusion_layer = build(fusion_layer)
+        self.pts_backbone = build(pts_backbone)
+        self.pts_neck = build(pts_neck)
+        self.bbox_head = build(bbox_head)
+
+    # ------------------------------------------------------------------ LiDAR branch
+    @torch.no_grad()
+    def voxelize(self, points: List[torch.Tensor]):
+        """(reference :227-255) per-sample hard voxelization, batch id prepended -> (b, x, y, z), mean reduce."""
+        feats, coords, sizes = [], [], []
+        for k, res in enumerate(points):
+            ret = self.pts_voxel_layer(res)
+            if len(ret) == 3:
+                f, c, n = ret
+            else:
+                assert len(ret) == 2
+                f, c = ret
+                n = None
+            feats.append(f)
+            coords.append(F.pad(c, (1, 0), mode="constant", value=k))
+            if n is not None:
+                sizes.append(n)
+        feats = torch.cat(feats, dim=0)
+        coords = torch.cat(coords, dim=0)
+        if len(sizes) > 0:
+            sizes = torch.cat(sizes, dim=0)
+            if self.voxelize_reduce:
+                feats = voxel_mean(feats, sizes)
+        return feats, coords, sizes
+
+    def extract_pts_feat(self, batch_inputs_dict) -> torch.Tensor:
+        points = batch_inputs_dict["points"]
+        with torch.autocast("cuda", enabled=False):
+            points = [p.float() for p in points]
+            feats, coords, sizes = self.voxelize(points)
+            batch_size = len(points)  # the reference reads coords[-1, 0] + 1 from the device (:206)
+            return self.pts_middle_encoder(feats, coords, batch_size)
+
+    # ------------------------------------------------------------------ camera branch
+    def extract_img_feat(self, x, points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
+                         lidar_aug_matrix, img_metas=None, geom_feats=None):
+        B, N, C, H, W = x.size()
+        x = self.img_backbone(x.view(B * N, C, H, W).contiguous())
+        x = self.img_neck(x)
+        if not isinstance(x, torch.Tensor):
+            x = x[0]
+        BN, C, H, W = x.size()
+        x = x.view(B, N, C, H, W)
+        with torch.autocast("cuda", enabled=False):  # fp32 island, as the reference (:177)
+            return self.view_transform(x.float(), points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
+                                       lidar_aug_matrix, img_metas, geom_feats_precomputed=geom_feats)
+
+    def extract_feat(self, batch_inputs_dict: Dict, batch_input_metas=None):
+        imgs = batch_inputs_dict.get("imgs", None)
+        points = batch_inputs_dict.get("points", None)
+        features = []
+        depth_loss = 0.0
+        if imgs is not None and self.view_transform is not None:
+            mats = {}
+            for key, meta_key in (("lidar2img", "lidar2img"), ("cam2img", "cam2img"), ("cam2lidar", "cam2lidar"),
+                                  ("img_aug_matrix", "img_aug_matrix"), ("lidar_aug_matrix", "lidar_aug_matrix")):
+                if key in batch_inputs_dict:
+                    mats[key] = batch_inputs_dict[key]
+                else:
+                    default = np.eye(4) if "aug" in key else None
+                    mats[key] = imgs.new_tensor(np.asarray([m.get(meta_key, default) for m in batch_input_metas]))
+            # the reference passes deepcopy(points) because its rasteriser mutates them (:326); ours does not
+            img_feature, depth_loss = self.extract_img_feat(imgs, points, mats["lidar2img"], mats["cam2img"],
+                                                            mats["cam2lidar"], mats["img_aug_matrix"],
+                                                            mats["lidar_aug_matrix"], batch_input_metas,
+                                                            geom_feats=batch_inputs_dict.get("geom_feats"))
+            features.append(img_feature)
+        if self.pts_middle_encoder is not None and points is not None:
+            features.append(self.extract_pts_feat(batch_inputs_dict))
+        if self.fusion_layer is not None:
+            x = self.fusion_layer(features)
+        else:
+            assert len(features) == 1, features
+            x = features[0]
+        x = self.pts_backbone(x)
+        x = self.pts_neck(x)
+        return x, depth_loss
+
+    def forward(self, batch_inputs_dict, batch_input_metas=None):
+        feats, depth_loss = self.extract_feat(batch_inputs_dict, batch_input_metas)
+        outs = self.bbox_head(feats, batch_input_metas) if self.bbox_head is not None else feats
+        return outs, depth_loss
+
+
+def nuscenes_config(camera=True, lidar=True):
+    """Model dict of the reference's nuScenes configs
+    (projects/BEVFusion/configs/nuscenes/bevfusion_lidar_voxel0075...py:44-131 and
+    bevfusion_lidar-cam_voxel0075...py:9-57) with BASELINE.json's ResNet-50 image backbone."""
+    cfg = dict(
+        type="BEVFusion",
+        data_preprocessor=dict(voxelize_cfg=dict(max_num_points=10, point_cloud_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0],
+                                                 voxel_size=[0.075, 0.075, 0.2], max_voxels=[120000, 160000],
+                                                 voxelize_reduce=True)),
+        pts_backbone=dict(type="SECOND", in_channels=256, out_channels=[128, 256], layer_nums=[5, 5],
+                          layer_strides=[1, 2], norm_cfg=dict(type="BN", eps=0.001, momentum=0.01)),
+        pts_neck=dict(type="SECONDFPN", in_channels=[128, 256], out_channels=[256, 256], upsample_strides=[1, 2],
+                      norm_cfg=dict(type="BN", eps=0.001, momentum=0.01), use_conv_for_no_stride=True),
+        bbox_head=dict(type="BEVFusionHead", num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128,
+                       num_classes=10, nms_kernel_size=3, bn_momentum=0.1, num_decoder_layers=1,
+                       decoder_layer=dict(self_attn_cfg=dict(embed_dims=128, num_heads=8, dropout=0.1),
+                                          cross_attn_cfg=dict(embed_dims=128, num_heads=8, dropout=0.1),
+                                          ffn_cfg=dict(embed_dims=128, feedforward_channels=256, num_fcs=2, ffn_drop=0.1),
+                                          pos_encoding_cfg=dict(input_channel=2, num_pos_feats=128)),
+                       common_heads=dict(center=[2, 2], height=[1, 2], dim=[3, 2], rot=[2, 2], vel=[2, 2])),
+    )
+    if lidar:
+        cfg["pts_middle_encoder"] = dict(
+            type="BEVFusionSparseEncoder", in_channels=5, sparse_shape=[1440, 1440, 41], order=("conv", "norm", "act"),
+            norm_cfg=dict(type="BN1d", eps=0.001, momentum=0.01),
+            encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+            encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, (1, 1, 0)), (0, 0)), block_type="basicblock")
+    if camera:
+        cfg["img_backbone"] = dict(type="ResNet50")
+        cfg["img_neck"] = dict(type="GeneralizedLSSFPN", in_channels=[512, 1024, 2048], out_channels=256, start_level=0,
+                               num_outs=3, upsample_cfg=dict(mode="bilinear", align_corners=False))
+        cfg["view_transform"] = dict(type="DepthLSSTransform", in_channels=256, out_channels=80, image_size=[256, 704],
+                                     feature_size=[32, 88], xbound=[-54.0, 54.0, 0.3], ybound=[-54.0, 54.0, 0.3],
+                                     zbound=[-10.0, 10.0, 20.0], dbound=[1.0, 60.0, 0.5], downsample=2)
+    if camera and lidar:
+        cfg["fusion_layer"] = dict(type="ConvFuser", in_channels=[80, 256], out_channels=256)
+    elif camera:
+        cfg["pts_backbone"]["in_channels"] = 80
+    return cfg
+
+
+def surrogate_loss(outs, depth_loss=0.0):
+    """Stand-in for BEVFusionHead.loss (BF/bevfusion_head.py:676-796), which needs the Hungarian assigner
+    (CPU + scipy in the reference, BF/utils.py:241-284) and GT boxes: a Gaussian-focal style term on the
+    dense heat-map plus L1 terms on every regression head, so that backward reaches every parameter the
+    real loss reaches.  Used by bench.py only; not a training objective."""
+    res = outs[0]
+    hm = res["dense_heatmap"].float().sigmoid().clamp(1e-4, 1 - 1e-4)
+    loss = -(torch.log(1 - hm) * hm.pow(2)).mean()
+    for key in ("center", "height", "dim", "rot", "vel", "heatmap"):
+        loss = loss + 0.25 * res[key].float().abs().mean()
+    if torch.is_tensor(depth_loss):
+        loss = loss + 0.0 * depth_loss  # the reference computes but does not add it (BF/bevfusion.py:388-392)
+    return loss

@@ -1,0 +1,313 @@
+"""Dense (MFMA-bound) modules of the BEVFusion graph, as plain torch.nn on ROCm (MIOpen / hipBLASLt).
+
+These are consumers/producers of the hot-path operators, not the product: they exist so that the full
+fwd+bwd step of BASELINE.json configs 3-5 can run without mmcv/mmdet/mmengine (absent in this image).
+Layer shapes follow the reference:
+  ResNet50            BASELINE.json's image backbone (the reference config uses mmdet Swin-T; any backbone
+                      returning 3 levels works, BF/bevfusion.py:55,161-171)
+  GeneralizedLSSFPN   BF/bevfusion_necks.py:11-96
+  ConvFuser           BF/bevfusion_head.py:25-38
+  SECOND / SECONDFPN  mmdet3d/models/backbones/second.py:27-95, mmdet3d/models/necks/second_fpn.py:30-94
+  BEVFusionHead       BF/bevfusion_head.py:41-299 (forward only: shared conv, heat-map head, top-k proposals,
+                      one TransformerDecoderLayer BF/transformer.py:26-113, SeparateHead
+                      mmdet3d/models/dense_heads/centerpoint_head.py:20-121).  Target assignment, losses and
+                      box decoding are "next" rows.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import MODELS
+
+
+# ----------------------------------------------------------------------------- image backbone
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+@MODELS.register_module()
+class ResNet50(nn.Module):
+    """Standard ResNet-50; returns the stride-8/16/32 maps (512, 1024, 2048 channels)."""
+
+    def __init__(self, out_indices=(1, 2, 3)):
+        super().__init__()
+        self.out_indices = out_indices
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.inplanes = 64
+        self.layer1 = self._make_layer(64, 3, 1)
+        self.layer2 = self._make_layer(128, 4, 2)
+        self.layer3 = self._make_layer(256, 6, 2)
+        self.layer4 = self._make_layer(512, 3, 2)
+
+    def _make_layer(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * 4))
+        layers = [_Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        layers += [_Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            x = layer(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+def _conv_module(cin, cout, k, padding=0, norm=True, act=True, eps=1e-5, momentum=0.1, stride=1):
+    layers = [nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=not norm)]
+    if norm:
+        layers.append(nn.BatchNorm2d(cout, eps=eps, momentum=momentum))
+    if act:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+@MODELS.register_module()
+class GeneralizedLSSFPN(nn.Module):
+    """Top-down: upsample level i+1, concat with level i, 1x1 conv, 3x3 conv; returns levels [0, n-1)."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, no_norm_on_lateral=False,
+                 conv_cfg=None, norm_cfg=dict(type="BN2d"), act_cfg=dict(type="ReLU"),
+                 upsample_cfg=dict(mode="bilinear", align_corners=True)):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.upsample_cfg = dict(upsample_cfg)
+        self.backbone_end_level = self.num_ins - 1 if end_level == -1 else end_level
+        self.start_level, self.end_level = start_level, end_level
+        self.lateral_convs, self.fpn_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(start_level, self.backbone_end_level):
+            cin = in_channels[i] + (in_channels[i + 1] if i == self.backbone_end_level - 1 else out_channels)
+            self.lateral_convs.append(_conv_module(cin, out_channels, 1, norm=not no_norm_on_lateral))
+            self.fpn_convs.append(_conv_module(out_channels, out_channels, 3, padding=1))
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [inputs[i + self.start_level] for i in range(len(inputs))]
+        used = len(laterals) - 1
+        for i in range(used - 1, -1, -1):
+            x = F.interpolate(laterals[i + 1], size=laterals[i].shape[2:], **self.upsample_cfg)
+            laterals[i] = self.fpn_convs[i](self.lateral_convs[i](torch.cat([laterals[i], x], dim=1)))
+        return tuple(laterals[i] for i in range(used))
+
+
+# ----------------------------------------------------------------------------- fusion + BEV backbone
+@MODELS.register_module()
+class ConvFuser(nn.Sequential):
+    def __init__(self, in_channels, out_channels):
+        self.in_channels, self.out_channels = in_channels, out_channels
+        super().__init__(nn.Conv2d(sum(in_channels), out_channels, 3, padding=1, bias=False),
+                         nn.BatchNorm2d(out_channels), nn.ReLU(True))
+
+    def forward(self, inputs):
+        return super().forward(torch.cat(inputs, dim=1))
+
+
+@MODELS.register_module()
+class SECOND(nn.Module):
+    def __init__(self, in_channels=128, out_channels=[128, 128, 256], layer_nums=[3, 5, 5], layer_strides=[2, 2, 2],
+                 norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False)):
+        super().__init__()
+        assert len(layer_strides) == len(layer_nums) == len(out_channels)
+        eps, mom = norm_cfg.get("eps", 1e-5), norm_cfg.get("momentum", 0.1)
+        in_filters = [in_channels, *out_channels[:-1]]
+        blocks = []
+        for i, n in enumerate(layer_nums):
+            block = [nn.Conv2d(in_filters[i], out_channels[i], 3, stride=layer_strides[i], padding=1, bias=False),
+                     nn.BatchNorm2d(out_channels[i], eps=eps, momentum=mom), nn.ReLU(inplace=True)]
+            for _ in range(n):
+                block += [nn.Conv2d(out_channels[i], out_channels[i], 3, padding=1, bias=False),
+                          nn.BatchNorm2d(out_channels[i], eps=eps, momentum=mom), nn.ReLU(inplace=True)]
+            blocks.append(nn.Sequential(*block))
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        outs = []
+        for b in self.blocks:
+            x = b(x)
+            outs.append(x)
+        return tuple(outs)
+
+
+@MODELS.register_module()
+class SECONDFPN(nn.Module):
+    def __init__(self, in_channels=[128, 128, 256], out_channels=[256, 256, 256], upsample_strides=[1, 2, 4],
+                 norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), upsample_cfg=dict(type="deconv", bias=False),
+                 conv_cfg=dict(type="Conv2d", bias=False), use_conv_for_no_stride=False):
+        super().__init__()
+        eps, mom = norm_cfg.get("eps", 1e-5), norm_cfg.get("momentum", 0.1)
+        deblocks = []
+        for i, oc in enumerate(out_channels):
+            s = upsample_strides[i]
+            if s > 1 or (s == 1 and not use_conv_for_no_stride):
+                up = nn.ConvTranspose2d(in_channels[i], oc, s, stride=s, bias=False)
+            else:
+                k = int(round(1 / s))
+                up = nn.Conv2d(in_channels[i], oc, k, stride=k, bias=False)
+            deblocks.append(nn.Sequential(up, nn.BatchNorm2d(oc, eps=eps, momentum=mom), nn.ReLU(inplace=True)))
+        self.deblocks = nn.ModuleList(deblocks)
+
+    def forward(self, x):
+        ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
+        return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]
+
+
+# ----------------------------------------------------------------------------- TransFusion head (forward)
+class PositionEncodingLearned(nn.Module):
+    def __init__(self, input_channel, num_pos_feats=288):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(nn.Conv1d(input_channel, num_pos_feats, 1),
+                                                     nn.BatchNorm1d(num_pos_feats), nn.ReLU(inplace=True),
+                                                     nn.Conv1d(num_pos_feats, num_pos_feats, 1))
+
+    def forward(self, xyz):
+        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+
+class _MHA(nn.Module):
+    """mmcv MultiheadAttention semantics: identity + dropout(attn(q + q_pos, k + k_pos, v)), batch_first."""
+
+    def __init__(self, embed_dims, num_heads, dropout=0.0):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, dropout=dropout, batch_first=True)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, query, key, value, query_pos=None, key_pos=None):
+        q = query if query_pos is None else query + query_pos
+        k = key if key_pos is None else key + key_pos
+        return query + self.dropout(self.attn(q, k, value, need_weights=False)[0])
+
+
+@MODELS.register_module()
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, self_attn_cfg=dict(embed_dims=128, num_heads=8, dropout=0.1),
+                 cross_attn_cfg=dict(embed_dims=128, num_heads=8, dropout=0.1),
+                 ffn_cfg=dict(embed_dims=128, feedforward_channels=256, num_fcs=2, ffn_drop=0.1),
+                 norm_cfg=dict(type="LN"), pos_encoding_cfg=dict(input_channel=2, num_pos_feats=128), **kwargs):
+        super().__init__()
+        d = self_attn_cfg["embed_dims"]
+        self.self_attn = _MHA(d, self_attn_cfg["num_heads"], self_attn_cfg.get("dropout", 0.0))
+        self.cross_attn = _MHA(d, cross_attn_cfg["num_heads"], cross_attn_cfg.get("dropout", 0.0))
+        ff, drop = ffn_cfg["feedforward_channels"], ffn_cfg.get("ffn_drop", 0.0)
+        self.ffn = nn.Sequential(nn.Linear(d, ff), nn.ReLU(inplace=True), nn.Dropout(drop), nn.Linear(ff, d),
+                                 nn.Dropout(drop))
+        self.norms = nn.ModuleList([nn.LayerNorm(d) for _ in range(3)])
+        self.self_posembed = PositionEncodingLearned(**pos_encoding_cfg)
+        self.cross_posembed = PositionEncodingLearned(**pos_encoding_cfg)
+
+    def forward(self, query, key=None, query_pos=None, key_pos=None):
+        """query [B, C, Nq], key [B, C, Nk], *_pos [B, N, 2] -> [B, C, Nq]."""
+        qp = self.self_posembed(query_pos).transpose(1, 2)
+        kp = self.cross_posembed(key_pos).transpose(1, 2)
+        q, k = query.transpose(1, 2), key.transpose(1, 2)
+        q = self.norms[0](self.self_attn(q, q, q + qp, qp, qp))
+        q = self.norms[1](self.cross_attn(q, k, k + kp, qp, kp))
+        q = self.norms[2](q + self.ffn(q))
+        return q.transpose(1, 2)
+
+
+class SeparateHead(nn.Module):
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, init_bias=-2.19):
+        super().__init__()
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            layers, c_in = [], in_channels
+            for _ in range(num_conv - 1):
+                layers += [nn.Conv1d(c_in, head_conv, final_kernel, padding=final_kernel // 2, bias=False),
+                           nn.BatchNorm1d(head_conv), nn.ReLU(inplace=True)]
+                c_in = head_conv
+            layers.append(nn.Conv1d(head_conv, classes, final_kernel, padding=final_kernel // 2, bias=True))
+            self.add_module(head, nn.Sequential(*layers))
+        getattr(self, "heatmap")[-1].bias.data.fill_(init_bias)
+
+    def forward(self, x):
+        return {head: getattr(self, head)(x) for head in self.heads}
+
+
+@MODELS.register_module()
+class BEVFusionHead(nn.Module):
+    """Forward of the TransFusion head (BF/bevfusion_head.py:198-299)."""
+
+    def __init__(self, num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
+                 num_decoder_layers=1, decoder_layer=dict(), num_heads=8, nms_kernel_size=3, bn_momentum=0.1,
+                 common_heads=dict(center=[2, 2], height=[1, 2], dim=[3, 2], rot=[2, 2], vel=[2, 2]),
+                 num_heatmap_convs=2, grid_size=(1440, 1440, 41), out_size_factor=8, **kwargs):
+        super().__init__()
+        self.num_classes, self.num_proposals = num_classes, num_proposals
+        self.num_decoder_layers, self.nms_kernel_size, self.auxiliary = num_decoder_layers, nms_kernel_size, auxiliary
+        self.shared_conv = nn.Conv2d(in_channels, hidden_channel, 3, padding=1)
+        self.heatmap_head = nn.Sequential(
+            nn.Conv2d(hidden_channel, hidden_channel, 3, padding=1, bias=False), nn.BatchNorm2d(hidden_channel),
+            nn.ReLU(inplace=True), nn.Conv2d(hidden_channel, num_classes, 3, padding=1))
+        self.class_encoding = nn.Conv1d(num_classes, hidden_channel, 1)
+        self.decoder = nn.ModuleList([TransformerDecoderLayer(**decoder_layer) for _ in range(num_decoder_layers)])
+        heads = dict(common_heads)
+        heads.update(heatmap=(num_classes, num_heatmap_convs))
+        self.prediction_heads = nn.ModuleList([SeparateHead(hidden_channel, heads) for _ in range(num_decoder_layers)])
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = bn_momentum
+        xs, ys = grid_size[0] // out_size_factor, grid_size[1] // out_size_factor
+        bx, by = torch.meshgrid(torch.linspace(0, xs - 1, xs), torch.linspace(0, ys - 1, ys), indexing="ij")
+        self.register_buffer("bev_pos", torch.stack([bx + 0.5, by + 0.5], 0).view(1, 2, -1).permute(0, 2, 1),
+                             persistent=False)
+
+    def forward(self, feats, metas=None):
+        inputs = feats[0] if isinstance(feats, (list, tuple)) else feats
+        B = inputs.shape[0]
+        fusion_feat = self.shared_conv(inputs)
+        flat = fusion_feat.view(B, fusion_feat.shape[1], -1)
+        bev_pos = self.bev_pos.expand(B, -1, -1)
+        with torch.autocast("cuda", enabled=False):
+            dense_heatmap = self.heatmap_head(fusion_feat.float())
+        heatmap = dense_heatmap.detach().sigmoid()
+        pad = self.nms_kernel_size // 2
+        local_max = torch.zeros_like(heatmap)
+        inner = F.max_pool2d(heatmap, kernel_size=self.nms_kernel_size, stride=1, padding=0)
+        local_max[:, :, pad:-pad, pad:-pad] = inner
+        heatmap = (heatmap * (heatmap == local_max)).view(B, heatmap.shape[1], -1)
+        top = heatmap.view(B, -1).topk(self.num_proposals, dim=-1).indices  # = argsort(descending)[:num_proposals]
+        top_class, top_index = top // heatmap.shape[-1], top % heatmap.shape[-1]
+        query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1), dim=-1)
+        one_hot = F.one_hot(top_class, num_classes=self.num_classes).permute(0, 2, 1)
+        query_feat = query_feat + self.class_encoding(one_hot.to(query_feat.dtype))
+        query_pos = bev_pos.gather(index=top_index[:, :, None].expand(-1, -1, 2), dim=1)
+        rets = []
+        for i in range(self.num_decoder_layers):
+            query_feat = self.decoder[i](query_feat, key=flat, query_pos=query_pos, key_pos=bev_pos)
+            res = self.prediction_heads[i](query_feat)
+            res["center"] = res["center"] + query_pos.permute(0, 2, 1)
+            rets.append(res)
+            query_pos = res["center"].detach().clone().permute(0, 2, 1)
+        rets[0]["query_heatmap_score"] = heatmap.gather(index=top_index[:, None, :].expand(-1, self.num_classes, -1), dim=-1)
+        rets[0]["dense_heatmap"] = dense_heatmap
+        rets[0]["query_labels"] = top_class
+        return rets

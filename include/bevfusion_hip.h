@@ -110,6 +110,28 @@ int bfhip_hard_voxelize(const float *points, int n, int f, float *voxels, int32_
                         void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * dynamic scatter  (replaces voxel_layer.dynamic_point_to_voxel_forward / _backward,
+ *   BF/ops/voxel/src/scatter_points_cuda.cu:183-308) and the hard-voxel mean (BF/bevfusion.py:251-253)
+ *   feats f32[N,C], coors i32[N,3]; rows with any negative coordinate are dropped (:202).
+ *   voxel rows come out in ascending lexicographic (c0,c1,c2) order, like at::unique_dim(sorted).
+ *   fwd outputs are sized for N rows; counts_dev i32[3] = {M voxels, valid points, key-overflow flag
+ *   (coordinates must be < 2^21)}.  Sums run in point order (deterministic).
+ *   bwd: sum/mean -> gather (mean divides by count); max -> gradient to the lowest-index arg-max.
+ * --------------------------------------------------------------------------------------- */
+size_t bfhip_dynamic_scatter_workspace_bytes(int N);
+int bfhip_dynamic_scatter_fwd(const float *feats, const int32_t *coors, int N, int C, int reduce_type,
+                              float *voxel_feats, int32_t *voxel_coors, int32_t *point2voxel,
+                              int32_t *voxel_count, int32_t *counts_dev, void *workspace,
+                              size_t workspace_bytes, void *stream);
+size_t bfhip_dynamic_scatter_bwd_workspace_bytes(int M, int C);
+int bfhip_dynamic_scatter_bwd(float *grad_feats, const float *grad_voxel_feats, const float *feats,
+                              const float *voxel_feats, const int32_t *point2voxel,
+                              const int32_t *voxel_count, int N, int M, int C, int reduce_type,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int bfhip_voxel_mean(const float *voxels, const int32_t *num_points, int M, int P, int F, float *out,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * camera frustum -> BEV plan  (replaces BaseViewTransform.get_geometry + bev_pool_aux,
  *   BF/depth_lss.py:68-112,118-176, and the interval construction of
  *   BF/ops/bev_pool/bev_pool.py:48-54; sync-free: all counts stay on the device)
