@@ -93,12 +93,12 @@ class BEVFusion(nn.Module):
     def extract_img_feat(self, x, points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
                          lidar_aug_matrix, img_metas=None, geom_feats=None):
         B, N, C, H, W = x.size()
-        x = self.img_backbone(x.view(B * N, C, H, W).contiguous())
+        x = self.img_backbone(x.reshape(B * N, C, H, W))
         x = self.img_neck(x)
         if not isinstance(x, torch.Tensor):
             x = x[0]
         BN, C, H, W = x.size()
-        x = x.view(B, N, C, H, W)
+        x = x.reshape(B, N, C, H, W)
         with torch.autocast("cuda", enabled=False):  # fp32 island, as the reference (:177)
             return self.view_transform(x.float(), points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
                                        lidar_aug_matrix, img_metas, geom_feats_precomputed=geom_feats)

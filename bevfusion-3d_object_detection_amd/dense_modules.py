@@ -284,7 +284,7 @@ class BEVFusionHead(nn.Module):
         inputs = feats[0] if isinstance(feats, (list, tuple)) else feats
         B = inputs.shape[0]
         fusion_feat = self.shared_conv(inputs)
-        flat = fusion_feat.view(B, fusion_feat.shape[1], -1)
+        flat = fusion_feat.reshape(B, fusion_feat.shape[1], -1)
         bev_pos = self.bev_pos.expand(B, -1, -1)
         with torch.autocast("cuda", enabled=False):
             dense_heatmap = self.heatmap_head(fusion_feat.float())
@@ -293,8 +293,8 @@ class BEVFusionHead(nn.Module):
         local_max = torch.zeros_like(heatmap)
         inner = F.max_pool2d(heatmap, kernel_size=self.nms_kernel_size, stride=1, padding=0)
         local_max[:, :, pad:-pad, pad:-pad] = inner
-        heatmap = (heatmap * (heatmap == local_max)).view(B, heatmap.shape[1], -1)
-        top = heatmap.view(B, -1).topk(self.num_proposals, dim=-1).indices  # = argsort(descending)[:num_proposals]
+        heatmap = (heatmap * (heatmap == local_max)).reshape(B, heatmap.shape[1], -1)
+        top = heatmap.reshape(B, -1).topk(self.num_proposals, dim=-1).indices  # = argsort(descending)[:num_proposals]
         top_class, top_index = top // heatmap.shape[-1], top % heatmap.shape[-1]
         query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1), dim=-1)
         one_hot = F.one_hot(top_class, num_classes=self.num_classes).permute(0, 2, 1)

@@ -167,7 +167,7 @@ class BaseViewTransform(nn.Module):
             extra_rots = torch.eye(3, device=dev).expand(B, 3, 3)
         if extra_trans is None:
             extra_trans = torch.zeros(B, 3, device=dev)
-        return plan.build(self.frustum.view(-1, 3), post_trans.reshape(B * N, 3), post_rots_inverse.reshape(B * N, 9),
+        return plan.build(self.frustum.reshape(-1, 3), post_trans.reshape(B * N, 3), post_rots_inverse.reshape(B * N, 9),
                           combine.reshape(B * N, 9), camera2lidar_trans.reshape(B * N, 3), extra_rots.reshape(B, 9),
                           extra_trans.reshape(B, 3), self._origin_host, self._dx_host)
 
@@ -205,7 +205,7 @@ class BaseViewTransform(nn.Module):
         B, N, D, H, W, C = x.shape
         x = x.reshape(B * N * D * H * W, C)
         geom_feats, kept, ranks, indices = self.bev_pool_aux(geom_feats)
-        return self.bev_pool_precomputed(x.view(B, N, D, H, W, C), geom_feats, kept, ranks, indices)
+        return self.bev_pool_precomputed(x.reshape(B, N, D, H, W, C), geom_feats, kept, ranks, indices)
 
     def bev_pool_precomputed(self, x, geom_feats, kept, ranks, indices):
         """(reference :206-223)"""
@@ -268,7 +268,7 @@ class LSSTransform(BaseViewTransform):
 
     def get_depth_and_feat(self, x):
         B, N, C, fH, fW = x.shape
-        x = self.depthnet(x.view(B * N, C, fH, fW))
+        x = self.depthnet(x.reshape(B * N, C, fH, fW))
         return x[:, :self.D].softmax(dim=1), x[:, self.D:self.D + self.C]
 
     def get_cam_feats(self, x):
@@ -277,7 +277,7 @@ class LSSTransform(BaseViewTransform):
         depth, feat = self.get_depth_and_feat(x)
         fH, fW = depth.shape[-2:]
         out = depth.unsqueeze(1) * feat.unsqueeze(2)
-        return out.view(B, N, self.C, self.D, fH, fW).permute(0, 1, 3, 4, 5, 2)
+        return out.reshape(B, N, self.C, self.D, fH, fW).permute(0, 1, 3, 4, 5, 2)
 
     def forward(self, *args, **kwargs):
         return self.downsample(super().forward(*args, **kwargs))
@@ -386,8 +386,8 @@ class DepthLSSTransform(BaseDepthTransform):
     def get_depth_and_feat(self, x, d):
         B, N, C, fH, fW = x.shape
         BN = B * N
-        d = d.view(BN, *d.shape[2:])
-        x = x.view(BN, C, fH, fW)
+        d = d.reshape(BN, *d.shape[2:])
+        x = x.reshape(BN, C, fH, fW)
         gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
         x = self.depthnet(torch.cat([self.dtransform(d), x], dim=1))
         depth = x[:, :self.D].softmax(dim=1)
@@ -403,7 +403,7 @@ class DepthLSSTransform(BaseDepthTransform):
         depth, feat, est, gt, counts = self.get_depth_and_feat(x, d)
         fH, fW = depth.shape[-2:]
         out = depth.unsqueeze(1) * feat.unsqueeze(2)
-        return out.view(B, N, self.C, self.D, fH, fW).permute(0, 1, 3, 4, 5, 2), est, gt, counts
+        return out.reshape(B, N, self.C, self.D, fH, fW).permute(0, 1, 3, 4, 5, 2), est, gt, counts
 
     def forward(self, *args, **kwargs):
         x, depth_loss = super().forward(*args, **kwargs)
