@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void subm_pairs_kernel(const int4 *__restrict_
     }
     pair_fwd[t] = found;
   }
+  // pair statistics: spread over 64 counters (one hot word saturates at ~88 atomics/us); summed by the host wrapper
   unsigned long long bal = __ballot(found >= 0);
-  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_pairs, __popcll(bal));
+  if (n_pairs && (threadIdx.x & 63) == 0 && bal) atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], __popcll(bal));
 }
 
 // ---------------------------------------------------------------------------- strided rulebook
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void sparse_pairs_kernel(const int4 *__restric
     pair_bwd[t] = o;
   }
   unsigned long long bal = __ballot(ok);
-  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_pairs, __popcll(bal));
+  if (n_pairs && (threadIdx.x & 63) == 0 && bal) atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], __popcll(bal));
 }
 
 // -------------------------------------------------------------------------------- weight packing
@@ -306,6 +307,120 @@ __global__ __launch_bounds__(256) void spconv_gemm_kernel(const float *__restric
     }
   }
   // C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long long row = row_base + r * 16 + lq * 4 + i;
+      if (row < n_rows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          int col = nt * 16 + lr;
+          if (col < Ndim) out[(size_t)row * Ndim + col] = acc[r][nt][i];
+        }
+      }
+    }
+}
+
+// Workgroup version: 4 waves share every weight tile through LDS (double buffered, one barrier per
+// (offset, 16-channel chunk) step); the workgroup skips offsets none of its 4*R*16 rows uses.
+// Weight traffic from L2 drops 4x versus the per-wave kernel above; A rows are still gathered per wave.
+template <int NT, int R>
+__global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__restrict__ in, int Kdim,
+                                                              const f32x4 *__restrict__ Wp,
+                                                              const int *__restrict__ pairs, int ld,
+                                                              int KV, int n_rows, int Ndim,
+                                                              float *__restrict__ out) {
+  __shared__ f32x4 sB[2][NT * 64];
+  __shared__ unsigned s_mask;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const long long row_base = ((long long)blockIdx.x * 4 + wv) * (R * 16);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int CC = Kdim >> 4;
+  if (tid == 0) s_mask = 0u;
+  __syncthreads();
+  // which offsets does this wave / workgroup need
+  unsigned wmask = 0u;
+  for (int k = 0; k < KV; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      long long row = row_base + r * 16 + lr;
+      any |= (row < n_rows) && (pairs[(size_t)k * ld + row] >= 0);
+    }
+    if (__any(any)) wmask |= 1u << k;
+  }
+  if (lane == 0 && wmask) atomicOr(&s_mask, wmask);
+  __syncthreads();
+  unsigned gmask = s_mask;
+
+  f32x4 acc[R][NT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int LOADS = (NT * 64 + 255) / 256;  // float4 per thread per weight tile
+  f32x4 pre[LOADS];
+  auto prefetch = [&](int k, int cc) {
+    const f32x4 *wp = Wp + ((size_t)(k * CC + cc) * NT) * 64;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int e = tid + i * 256;
+      if (e < NT * 64) pre[i] = wp[e];
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int e = tid + i * 256;
+      if (e < NT * 64) sB[buf][e] = pre[i];
+    }
+  };
+  int k = gmask ? __ffs(gmask) - 1 : KV;
+  int cc = 0, buf = 0;
+  if (k < KV) prefetch(k, 0);
+  int idx[R];
+  while (k < KV) {
+    stash(buf);
+    __syncthreads();
+    // next step
+    int nk = k, ncc = cc + 1;
+    if (ncc == CC) {
+      ncc = 0;
+      unsigned rest = gmask & ~((2u << k) - 1u);
+      nk = rest ? __ffs(rest) - 1 : KV;
+    }
+    if (nk < KV) prefetch(nk, ncc);
+    if ((wmask >> k) & 1u) {
+      if (cc == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          long long row = row_base + r * 16 + lr;
+          idx[r] = row < n_rows ? pairs[(size_t)k * ld + row] : -1;
+        }
+      }
+      f32x4 a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        a[r] = idx[r] >= 0 ? *(const f32x4 *)(in + (size_t)idx[r] * Kdim + cc * 16 + lq * 4)
+                           : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = sB[buf][nt * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[nt][j], acc[r][nt], 0, 0, 0);
+    }
+    k = nk;
+    cc = ncc;
+    buf ^= 1;
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -426,6 +541,77 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float *__restri
     }
 }
 
+// v2: one wave = (offset k, row split s, 64-ci block, 64-co block).  Per K-step of 4 rows every lane
+// loads ONE float4 of in (row n0+q, channels 4a..4a+3) and ONE float4 of dout; the 16 MFMAs (c,d) then use
+// element c of the first and element d of the second:  D_cd[a][a'] += in[row][4a+c] * dout[row][4a'+d],
+// i.e. a 64x64 block of dW with channel index 4*lane_id + component.  2 coalesced 16-B loads per 16 MFMAs.
+__global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__restrict__ in, int Cin,
+                                                             const float *__restrict__ dout, int Cout,
+                                                             const int *__restrict__ pairs, int ld,
+                                                             int KV, int n_rows, int S, int GI, int GJ,
+                                                             float *__restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long total = (long long)KV * S * GI * GJ;
+  if (wave >= total) return;
+  const int gj = (int)(wave % GJ); wave /= GJ;
+  const int gi = (int)(wave % GI); wave /= GI;
+  const int s = (int)(wave % S);
+  const int k = (int)(wave / S);
+  const int la = lane & 15, lq = lane >> 4;
+  const int rows_per = (((n_rows + S - 1) / S) + 3) & ~3;
+  const int r0 = s * rows_per, r1 = min(n_rows, r0 + rows_per);
+  const int ci = gi * 64 + la * 4, co = gj * 64 + la * 4;
+  const bool ci_ok = ci < Cin, co_ok = co < Cout;  // Cin, Cout multiples of 4 (checked by the host)
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;
+  for (int n0 = r0; n0 < r1; n0 += 4 * U) {
+    int p[U];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int row = n0 + 4 * u + lq;
+      p[u] = row < r1 ? pairs[(size_t)k * ld + row] : -1;
+      any |= p[u] >= 0;
+    }
+    if (!__any(any)) continue;
+    f32x4 av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int row = n0 + 4 * u + lq;
+      bool ok = p[u] >= 0;
+      av[u] = (ok && ci_ok) ? *(const f32x4 *)(in + (size_t)p[u] * Cin + ci) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      bv[u] = (ok && co_ok) ? *(const f32x4 *)(dout + (size_t)row * Cout + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
+  }
+  // D layout: row = (lane>>4)*4 + i -> a (ci = 4a + c), col = lane&15 -> a' (co = 4a' + d)
+  float *dst = partial + ((size_t)s * KV + k) * Cin * Cout;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int cii = gi * 64 + (lq * 4 + i) * 4 + c;
+      if (cii < Cin) {
+        int coo = gj * 64 + la * 4;
+        if (coo < Cout) {
+          f32x4 v = (f32x4){acc[c][0][i], acc[c][1][i], acc[c][2][i], acc[c][3][i]};
+          *(f32x4 *)(dst + (size_t)cii * Cout + coo) = v;
+        }
+      }
+    }
+}
+
 // dW[co][k][ci] = sum_s partial[s][k][ci][co]   (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S,
                                                            int KV, int Cin, int Cout,
@@ -502,14 +688,14 @@ inline int make_geom(int B, const int *in_shape, const int *ksize, const int *st
 template <int NT>
 void launch_gemm(int R, int blocks_rows, hipStream_t stream, const float *in, int Kdim,
                  const f32x4 *Wp, const int *pairs, int ld, int KV, int n_rows, int Ndim, float *out) {
-  auto grid = [&](int r) { return dim3(ceil_div((long long)ceil_div(n_rows, r * 16) * 64, 256)); };
+  auto grid = [&](int r) { return dim3(ceil_div(n_rows, 4 * r * 16)); };  // one workgroup = 4 waves x r*16 rows
   (void)blocks_rows;
   if (R == 1)
-    hipLaunchKernelGGL((spconv_gemm_kernel<NT, 1>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
+    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 1>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
   else if (R == 2)
-    hipLaunchKernelGGL((spconv_gemm_kernel<NT, 2>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
+    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 2>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
   else
-    hipLaunchKernelGGL((spconv_gemm_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
+    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
 }
 
 }  // namespace
@@ -540,7 +726,7 @@ BFHIP_EXPORT int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const
   BFHIP_REQUIRE(make_geom(B, in_shape, ksize, nullptr, nullptr, dilation, true, G) == 0,
                 "rulebook_subm: bad geometry (B*X*Y*Z must be < 2^31, kernel volume <= 64)");
   BFHIP_REQUIRE(n_pairs_dev, "rulebook_subm: n_pairs_dev is null");
-  if (hipMemsetAsync(n_pairs_dev, 0, sizeof(int), stream) != hipSuccess) return check_launch("rulebook_subm memset");
+  if (hipMemsetAsync(n_pairs_dev, 0, 64 * sizeof(int), stream) != hipSuccess) return check_launch("rulebook_subm memset");
   if (N == 0) return BFHIP_OK;
   BFHIP_REQUIRE(indices && pair_fwd && ((uintptr_t)indices % 16) == 0, "rulebook_subm: null/unaligned pointer");
   if (workspace_bytes < bfhip_rulebook_subm_workspace_bytes(N) || !workspace) {
@@ -566,7 +752,8 @@ BFHIP_EXPORT int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const
 
 // Strided rulebook, two phases (the output row count must reach the host to size the outputs):
 //   count: bitmap over the output grid + prefix popcounts -> counts_dev[0] = N_out
-//   fill : out_indices (ascending linear order), pair_fwd[KV, ld_out], pair_bwd[KV, N], counts_dev[1] = pairs
+//   fill : out_indices (ascending linear order), pair_fwd[KV, ld_out], pair_bwd[KV, N],
+//          sum(counts_dev[1..64]) = pairs (64 spread counters: one hot word would serialise the atomics)
 // The workspace must be kept untouched between the two calls.
 BFHIP_EXPORT size_t bfhip_rulebook_sparse_workspace_bytes(int B, const int *in_shape, const int *ksize,
                                                           const int *stride, const int *padding,
@@ -600,7 +787,7 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_count(const int32_t *indices, int N, int 
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
   hipMemsetAsync(bitmap, 0, nwords * sizeof(unsigned), stream);
-  hipMemsetAsync(counts_dev, 0, 2 * sizeof(int), stream);
+  hipMemsetAsync(counts_dev, 0, 65 * sizeof(int), stream);
   if (N > 0) {
     long long total = (long long)G.KV * N;
     hipLaunchKernelGGL(sparse_mark_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, (const int4 *)indices, N, G, bitmap);
@@ -671,8 +858,10 @@ BFHIP_EXPORT int bfhip_spconv_gemm(const float *in, const float *W, const int32_
     hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, W, Cout, KV, Cin, transpose,
                        flip, CC, NT, Wp);
     // rows per wave: keep >= ~2 waves per SIMD when the tensor is small
-    int R = n_rows >= 262144 ? 4 : (n_rows >= 65536 ? 2 : 1);
+    // rows per wave: aim for >= ~1024 workgroups (4 per CU); a workgroup covers 4*R*16 rows
+    int R = n_rows >= 262144 ? 4 : (n_rows >= 131072 ? 2 : 1);
     if (NT == 8 && R == 4) R = 2;
+    BFHIP_REQUIRE(KV <= 32, "spconv_gemm: kernel volume > 32 is not supported by the MFMA path");
     const f32x4 *wp = (const f32x4 *)Wp;
     switch (NT) {
       case 1: launch_gemm<1>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, out); break;
@@ -701,7 +890,7 @@ static inline int wgrad_splits(int KV, int GI, int GJ, int n_rows) {
 }
 
 BFHIP_EXPORT size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout, int n_rows) {
-  int GI = (Cin + 31) / 32, GJ = (Cout + 63) / 64;
+  int GI = (Cin + 63) / 64, GJ = (Cout + 63) / 64;
   int S = wgrad_splits(KV, GI, GJ, n_rows);
   return align_up((size_t)S * KV * Cin * Cout * sizeof(float), 256) + 256;
 }
@@ -717,15 +906,20 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const float *in, const float *dout, const in
     return BFHIP_OK;
   }
   BFHIP_REQUIRE(in && dout && pairs, "spconv_wgrad: null pointer");
-  int GI = (Cin + 31) / 32, GJ = (Cout + 63) / 64;  // tile group = 2 ci-tiles x 4 co-tiles
-  int S = wgrad_splits(KV, GI, GJ, n_rows);
+  const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)dout % 16 == 0);
+  int GI = vec ? (Cin + 63) / 64 : (Cin + 31) / 32, GJ = (Cout + 63) / 64;
+  int S = wgrad_splits(KV, (Cin + 63) / 64, GJ, n_rows);
   if (workspace_bytes < bfhip_spconv_wgrad_workspace_bytes(KV, Cin, Cout, n_rows) || !workspace) { set_error("spconv_wgrad: workspace too small"); return BFHIP_E_WORKSPACE; }
   float *partial = (float *)workspace;
   long long waves = (long long)KV * S * GI * GJ;
   ProfScope ps;
   prof_begin(BFHIP_OP_SPCONV_BWD, stream, &ps);
-  hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
-                     pairs, ld, KV, n_rows, S, GI, GJ, partial);
+  if (vec)
+    hipLaunchKernelGGL(spconv_wgrad64_kernel, dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
+                       pairs, ld, KV, n_rows, S, GI, GJ, partial);
+  else
+    hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
+                       pairs, ld, KV, n_rows, S, GI, GJ, partial);
   long long total = (long long)KV * Cin * Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, partial, S, KV, Cin, Cout, dW);
   prof_end(&ps);

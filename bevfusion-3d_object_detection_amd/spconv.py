@@ -42,7 +42,7 @@ class IndiceData:
         self.out_indices = out_indices      # i32[N_out, 4]
         self.pair_fwd = pair_fwd            # i32[KV, N_out]
         self.pair_bwd = pair_bwd            # i32[KV, N_in] (None for SubM: pair_fwd with flipped offsets)
-        self.n_pairs = n_pairs              # device i32[1]
+        self.n_pairs = n_pairs              # device i32[64] spread counters; total pairs = n_pairs.sum()
         self.is_subm = is_subm
         self.out_spatial_shape = out_spatial_shape
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
@@ -53,7 +53,7 @@ def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation):
     kv = ksize[0] * ksize[1] * ksize[2]
     dev = indices.device
     pair_fwd = torch.empty((kv, N), dtype=torch.int32, device=dev)
-    n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_pairs = torch.zeros(64, dtype=torch.int32, device=dev)  # 64 spread counters; total = sum
     lib = _lib.load()
     ws = _workspace(dev, lib.bfhip_rulebook_subm_workspace_bytes(N), "rule")
     with torch.cuda.device(dev):
@@ -80,7 +80,7 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
     if nbytes == 0:
         raise RuntimeError("SparseConv3d: unsupported geometry")
     ws = _workspace(dev, nbytes, "rule")
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    counts = torch.zeros(65, dtype=torch.int32, device=dev)  # [N_out, 64 spread pair counters]
     stream = _lib.stream_of(indices)
     with torch.cuda.device(dev):
         rc = lib.bfhip_rulebook_sparse_count(_lib.ptr(indices), N, batch_size, *geo, _lib.ptr(counts), _lib.ptr(ws),

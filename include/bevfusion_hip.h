@@ -190,7 +190,9 @@ int bfhip_lift_splat_bwd(const float *out_grad, const float *depth, int depth_pi
  *           output rows in ASCENDING LINEAR ORDER ((b*X+x)*Y+y)*Z+z (canonical; spconv's is hash order).
  *           Two phases because N_out must reach the host: _count writes counts_dev[0] = N_out;
  *           _fill (same workspace, untouched in between) writes out_indices i32[n_out,4],
- *           pair_fwd i32[KV,n_out], pair_bwd i32[KV,N] and counts_dev[1] = number of pairs.
+ *           pair_fwd i32[KV,n_out], pair_bwd i32[KV,N]; the number of pairs is sum(counts_dev[1..64])
+ *           (counts_dev is i32[65]; rulebook_subm's n_pairs_dev is i32[64], same convention: 64 spread
+ *           counters, because one hot word serialises the atomics).
  * gemm    : out[n_rows, Ndim] = sum_k M_k . in[pairs[k][row]];  transpose=0 forward (M_k = W[:,k,:]^T),
  *           transpose=1 dgrad (M_k = W[:,k',:], k' = KV-1-k when flip else k; flip=1 lets a SubM layer
  *           reuse pair_fwd as its backward table).  Exact-fp32 MFMA, deterministic, no atomics.

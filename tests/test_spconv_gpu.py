@@ -35,7 +35,7 @@ def test_subm_rulebook_bit_exact(dev):
     want = oracle.rulebook_subm(idx, shape, 3)
     data = build_subm_rulebook(torch.from_numpy(idx).to(dev), 2, shape, [3, 3, 3], [1, 1, 1])
     assert np.array_equal(data.pair_fwd.cpu().numpy(), want)
-    assert int(data.n_pairs.item()) == (want >= 0).sum()
+    assert int(data.n_pairs.sum().item()) == (want >= 0).sum()
     # symmetry used by the SubM backward: pair[k][n] = j  <=>  pair[KV-1-k][j] = n
     pf = data.pair_fwd.cpu().numpy()
     k, n = np.nonzero(pf >= 0)
@@ -58,7 +58,7 @@ def test_sparse_rulebook_bit_exact(dev, shape, ksize, stride, padding):
     assert np.array_equal(data.out_indices.cpu().numpy(), out_idx)
     assert np.array_equal(data.pair_fwd.cpu().numpy(), pf)
     assert np.array_equal(data.pair_bwd.cpu().numpy(), pb)
-    assert int(data.n_pairs.item()) == (pf >= 0).sum()
+    assert int(data.n_pairs.sum().item()) == (pf >= 0).sum()
 
 
 @pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 64), (64, 64), (128, 128), (7, 9)])
