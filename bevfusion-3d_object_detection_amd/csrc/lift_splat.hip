@@ -216,6 +216,19 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const int *__restrict
 // ------------------------------------------------------------------------------ fused forward
 constexpr int kU = 8;
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap so that each
+// XCD walks one CONTIGUOUS eighth of the work: consecutive intervals (adjacent BEV cells) gather
+// neighbouring feature rows, and consecutive pixels gather neighbouring out_grad rows, so each XCD's
+// 4 MiB L2 then holds its own slice of the gathered table.  Bijective for any grid size; speed only.
+__device__ __forceinline__ long long xcd_chunked_block(long long bid, long long nblocks) {
+  const long long per = (nblocks + 7) / 8;      // blocks per XCD slice (last slices may be short)
+  const long long xcd = bid & 7, slot = bid >> 3;
+  const long long full = nblocks - (per - 1) * 8;  // number of slices that hold `per` blocks (1..8)
+  // slices [0, full) have `per` blocks, the rest have per-1
+  long long base = xcd < full ? xcd * per : full * per + (xcd - full) * (per - 1);
+  return base + slot;
+}
+
 // cq lanes per interval, each lane owns 4 channels.  out[cell][c] = sum_i depth[pix_i, d_i] * feat[pix_i, c]
 __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
     const float *__restrict__ depth, int depth_pitch, const float *__restrict__ feat, int feat_pitch,
@@ -224,7 +237,12 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
     int groups, float4 *__restrict__ out) {
   const int m = min(mmax, counts[1]);
   const int lane = threadIdx.x & (kWave - 1);
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // only the blocks that hold live intervals take part in the remap (m is a device-side count)
+  const long long waves_per_block = blockDim.x >> 6;
+  const long long live_blocks = ((long long)m + groups * waves_per_block - 1) / (groups * waves_per_block);
+  if ((long long)blockIdx.x >= live_blocks) return;
+  const long long bid = xcd_chunked_block(blockIdx.x, live_blocks);
+  const long long wave = bid * waves_per_block + (threadIdx.x >> 6);
   const int g = lane / cq;
   const int q = lane - g * cq;
   const long long k = wave * groups + g;
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
     int D, int HW, int cq, int groups, float *__restrict__ d_depth, int d_depth_pitch,
     float *__restrict__ d_feat, int d_feat_pitch) {
   const int lane = threadIdx.x & (kWave - 1);
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long wave = xcd_chunked_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int g = lane / cq;
   const int q = lane - g * cq;
   const long long p = wave * groups + g;
