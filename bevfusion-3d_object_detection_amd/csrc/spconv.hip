@@ -20,6 +20,9 @@
 //            reduced in a fixed order.
 #include "common.h"
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 namespace bfhip {
 namespace {
 
@@ -229,6 +232,21 @@ __global__ __launch_bounds__(256) void sparse_pairs_kernel(const int4 *__restric
   if (n_pairs && (threadIdx.x & 63) == 0 && bal) atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], __popcll(bal));
 }
 
+// -------------------------------------------------------------------------------- row masks
+// mask[n] bit k = pair[k][n] >= 0.  Rows are then sorted by mask so that the 16 rows of an MFMA tile
+// use (nearly) the same kernel offsets and whole offsets can be skipped per tile (the idea of spconv's
+// mask_argsort, projects/SparseConvolution/sparse_functional.py:139-162).
+__global__ __launch_bounds__(256) void row_mask_kernel(const int *__restrict__ pairs, int ld, int KV,
+                                                       int n_rows, unsigned *__restrict__ mask,
+                                                       unsigned *__restrict__ iota) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_rows) return;
+  unsigned m = 0u;
+  for (int k = 0; k < KV; ++k) m |= (pairs[(size_t)k * ld + n] >= 0 ? 1u : 0u) << k;
+  mask[n] = m;
+  iota[n] = (unsigned)n;
+}
+
 // -------------------------------------------------------------------------------- weight packing
 // Wp[((k*CC + cc)*NT + nt)*64 + lane][j] = M_k[cc*16 + 4*(lane>>4) + j][nt*16 + (lane&15)]
 //   forward : M_k[ci][co] = W[co][k][ci]                      (K = C_in,  N = C_out)
@@ -330,6 +348,8 @@ __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__res
                                                               const f32x4 *__restrict__ Wp,
                                                               const int *__restrict__ pairs, int ld,
                                                               int KV, int n_rows, int Ndim,
+                                                              const int *__restrict__ perm,
+                                                              const unsigned *__restrict__ row_mask,
                                                               float *__restrict__ out) {
   __shared__ f32x4 sB[2][NT * 64];
   __shared__ unsigned s_mask;
@@ -340,16 +360,28 @@ __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__res
   const int CC = Kdim >> 4;
   if (tid == 0) s_mask = 0u;
   __syncthreads();
+  // rows of this wave: position in mask-sorted order -> actual row
+  int my_row[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    long long sp = row_base + r * 16 + lr;
+    my_row[r] = sp < n_rows ? (perm ? perm[sp] : (int)sp) : -1;
+  }
   // which offsets does this wave / workgroup need
   unsigned wmask = 0u;
-  for (int k = 0; k < KV; ++k) {
-    bool any = false;
+  if (row_mask) {
+    unsigned mm = 0u;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      long long row = row_base + r * 16 + lr;
-      any |= (row < n_rows) && (pairs[(size_t)k * ld + row] >= 0);
+    for (int r = 0; r < R; ++r) mm |= my_row[r] >= 0 ? row_mask[my_row[r]] : 0u;
+    for (int o = 32; o > 0; o >>= 1) mm |= __shfl_xor(mm, o);
+    wmask = mm;
+  } else {
+    for (int k = 0; k < KV; ++k) {
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) any |= (my_row[r] >= 0) && (pairs[(size_t)k * ld + my_row[r]] >= 0);
+      if (__any(any)) wmask |= 1u << k;
     }
-    if (__any(any)) wmask |= 1u << k;
   }
   if (lane == 0 && wmask) atomicOr(&s_mask, wmask);
   __syncthreads();
@@ -396,10 +428,7 @@ __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__res
     if ((wmask >> k) & 1u) {
       if (cc == 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          long long row = row_base + r * 16 + lr;
-          idx[r] = row < n_rows ? pairs[(size_t)k * ld + row] : -1;
-        }
+        for (int r = 0; r < R; ++r) idx[r] = my_row[r] >= 0 ? pairs[(size_t)k * ld + my_row[r]] : -1;
       }
       f32x4 a[R];
 #pragma unroll
@@ -421,12 +450,13 @@ __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__res
     cc = ncc;
     buf ^= 1;
   }
+  // C/D layout: col = lane&15, row = (lane>>4)*4 + i ; the actual output row lives in lane (lq*4+i) of my_row
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      long long row = row_base + r * 16 + lq * 4 + i;
-      if (row < n_rows) {
+      int row = __shfl(my_row[r], lq * 4 + i);
+      if (row >= 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           int col = nt * 16 + lr;
@@ -549,6 +579,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__rest
                                                              const float *__restrict__ dout, int Cout,
                                                              const int *__restrict__ pairs, int ld,
                                                              int KV, int n_rows, int S, int GI, int GJ,
+                                                             const int *__restrict__ perm,
                                                              float *__restrict__ partial) {
   const int lane = threadIdx.x & 63;
   long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -570,22 +601,22 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__rest
     for (int d = 0; d < 4; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int U = 4;
   for (int n0 = r0; n0 < r1; n0 += 4 * U) {
-    int p[U];
+    int p[U], rw[U];
     bool any = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int row = n0 + 4 * u + lq;
-      p[u] = row < r1 ? pairs[(size_t)k * ld + row] : -1;
+      int sp = n0 + 4 * u + lq;  // position in mask-sorted order
+      rw[u] = sp < r1 ? (perm ? perm[sp] : sp) : -1;
+      p[u] = rw[u] >= 0 ? pairs[(size_t)k * ld + rw[u]] : -1;
       any |= p[u] >= 0;
     }
     if (!__any(any)) continue;
     f32x4 av[U], bv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int row = n0 + 4 * u + lq;
       bool ok = p[u] >= 0;
       av[u] = (ok && ci_ok) ? *(const f32x4 *)(in + (size_t)p[u] * Cin + ci) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      bv[u] = (ok && co_ok) ? *(const f32x4 *)(dout + (size_t)row * Cout + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      bv[u] = (ok && co_ok) ? *(const f32x4 *)(dout + (size_t)rw[u] * Cout + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -687,15 +718,16 @@ inline int make_geom(int B, const int *in_shape, const int *ksize, const int *st
 
 template <int NT>
 void launch_gemm(int R, int blocks_rows, hipStream_t stream, const float *in, int Kdim,
-                 const f32x4 *Wp, const int *pairs, int ld, int KV, int n_rows, int Ndim, float *out) {
+                 const f32x4 *Wp, const int *pairs, int ld, int KV, int n_rows, int Ndim, const int *perm,
+                 const unsigned *row_mask, float *out) {
   auto grid = [&](int r) { return dim3(ceil_div(n_rows, 4 * r * 16)); };  // one workgroup = 4 waves x r*16 rows
   (void)blocks_rows;
   if (R == 1)
-    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 1>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
+    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 1>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
   else if (R == 2)
-    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 2>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
+    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 2>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
   else
-    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, out);
+    hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
 }
 
 }  // namespace
@@ -831,6 +863,39 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B
   return check_launch("rulebook_sparse_fill");
 }
 
+// Row masks + mask-sorted row permutation of a pair table (for tile-level offset skipping).
+static inline size_t sort32_bytes(int n, int bits) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs<rocprim::default_config, unsigned *, unsigned *, unsigned *, unsigned *>(
+      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, bits, 0);
+  return bytes;
+}
+
+BFHIP_EXPORT size_t bfhip_rulebook_sort_rows_workspace_bytes(int n_rows, int KV) {
+  if (n_rows <= 0) return 256;
+  return 2 * align_up((size_t)n_rows * 4, 256) + align_up(sort32_bytes(n_rows, KV > 0 ? KV : 1), 256) + 256;
+}
+
+BFHIP_EXPORT int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, int n_rows, uint32_t *row_mask,
+                                          int32_t *perm, void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BFHIP_REQUIRE(KV > 0 && KV <= 32 && n_rows >= 0 && ld >= n_rows, "rulebook_sort_rows: bad sizes");
+  if (n_rows == 0) return BFHIP_OK;
+  BFHIP_REQUIRE(pairs && row_mask && perm, "rulebook_sort_rows: null pointer");
+  if (workspace_bytes < bfhip_rulebook_sort_rows_workspace_bytes(n_rows, KV) || !workspace) { set_error("rulebook_sort_rows: workspace too small"); return BFHIP_E_WORKSPACE; }
+  Workspace ws(workspace, workspace_bytes);
+  unsigned *iota = ws.take<unsigned>(n_rows), *keys_out = ws.take<unsigned>(n_rows);
+  size_t sb = sort32_bytes(n_rows, KV);
+  char *tmp = ws.take<char>(sb);
+  ProfScope ps;
+  prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
+  hipLaunchKernelGGL(row_mask_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, stream, pairs, ld, KV, n_rows, row_mask, iota);
+  hipError_t e = rocprim::radix_sort_pairs(tmp, sb, row_mask, keys_out, iota, (unsigned *)perm, (size_t)n_rows, 0, KV, stream);
+  prof_end(&ps);
+  if (e != hipSuccess) { set_error("rulebook_sort_rows: sort: %s", hipGetErrorString(e)); return BFHIP_E_LAUNCH; }
+  return check_launch("rulebook_sort_rows");
+}
+
 // Gather-GEMM: out[n_rows, Ndim] = sum_k M_k . in[pairs[k][row]]  with M_k derived from W (Cout,KV,Cin):
 //   transpose=0: forward  (Kdim = Cin,  Ndim = Cout)
 //   transpose=1: dgrad    (Kdim = Cout, Ndim = Cin); flip=1 uses W[KV-1-k] (SubM with pair_fwd as pair_bwd)
@@ -840,7 +905,8 @@ BFHIP_EXPORT size_t bfhip_spconv_workspace_bytes(int KV, int Cin, int Cout) {
 }
 
 BFHIP_EXPORT int bfhip_spconv_gemm(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
-                                   int n_rows, int Cin, int Cout, int transpose, int flip, float *out,
+                                   int n_rows, int Cin, int Cout, int transpose, int flip,
+                                   const int32_t *perm, const uint32_t *row_mask, float *out,
                                    void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(KV > 0 && Cin > 0 && Cout > 0 && n_rows >= 0 && ld >= n_rows, "spconv_gemm: bad sizes");
@@ -864,10 +930,10 @@ BFHIP_EXPORT int bfhip_spconv_gemm(const float *in, const float *W, const int32_
     BFHIP_REQUIRE(KV <= 32, "spconv_gemm: kernel volume > 32 is not supported by the MFMA path");
     const f32x4 *wp = (const f32x4 *)Wp;
     switch (NT) {
-      case 1: launch_gemm<1>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, out); break;
-      case 2: launch_gemm<2>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, out); break;
-      case 4: launch_gemm<4>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, out); break;
-      default: launch_gemm<8>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, out); break;
+      case 1: launch_gemm<1>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      case 2: launch_gemm<2>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      case 4: launch_gemm<4>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      default: launch_gemm<8>(R, 0, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
     }
   } else {
     long long total = (long long)n_rows * Ndim;
@@ -896,8 +962,8 @@ BFHIP_EXPORT size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout
 }
 
 BFHIP_EXPORT int bfhip_spconv_wgrad(const float *in, const float *dout, const int32_t *pairs, int ld, int KV,
-                                    int n_rows, int Cin, int Cout, float *dW, void *workspace,
-                                    size_t workspace_bytes, void *stream_) {
+                                    int n_rows, int Cin, int Cout, const int32_t *perm, float *dW,
+                                    void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(KV > 0 && Cin > 0 && Cout > 0 && n_rows >= 0 && ld >= n_rows, "spconv_wgrad: bad sizes");
   BFHIP_REQUIRE(dW, "spconv_wgrad: dW is null");
@@ -916,7 +982,7 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const float *in, const float *dout, const in
   prof_begin(BFHIP_OP_SPCONV_BWD, stream, &ps);
   if (vec)
     hipLaunchKernelGGL(spconv_wgrad64_kernel, dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
-                       pairs, ld, KV, n_rows, S, GI, GJ, partial);
+                       pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
   else
     hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
                        pairs, ld, KV, n_rows, S, GI, GJ, partial);

@@ -46,6 +46,26 @@ class IndiceData:
         self.is_subm = is_subm
         self.out_spatial_shape = out_spatial_shape
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+        # mask-sorted row orders (tile-level offset skipping): forward table and, for strided convs, backward table
+        self.mask_fwd, self.perm_fwd = sort_rows(pair_fwd)
+        self.mask_bwd, self.perm_bwd = sort_rows(pair_bwd) if pair_bwd is not None else (None, None)
+
+
+def sort_rows(pairs):
+    """(row_mask u32[n], perm i32[n]) of a pair table i32[KV, n] (bfhip_rulebook_sort_rows)."""
+    kv, n = pairs.shape
+    dev = pairs.device
+    mask = torch.empty(n, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    if n == 0:
+        return mask, perm
+    lib = _lib.load()
+    ws = _workspace(dev, lib.bfhip_rulebook_sort_rows_workspace_bytes(n, kv), "rule")
+    with torch.cuda.device(dev):
+        rc = lib.bfhip_rulebook_sort_rows(_lib.ptr(pairs), n, kv, n, _lib.ptr(mask), _lib.ptr(perm), _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_of(pairs))
+    _lib.check(rc, "rulebook_sort_rows")
+    return mask, perm
 
 
 def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation):
@@ -98,7 +118,7 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
                       conv_out_shape(spatial_shape, ksize, stride, padding, dilation), ksize, stride, padding, dilation)
 
 
-def _gemm(inp, weight, pairs, n_rows, transpose, flip):
+def _gemm(inp, weight, pairs, n_rows, transpose, flip, perm=None, row_mask=None):
     cout, cin = weight.shape[0], weight.shape[-1]
     kv = pairs.shape[0]
     out = torch.empty((n_rows, cin if transpose else cout), dtype=torch.float32, device=inp.device)
@@ -106,8 +126,8 @@ def _gemm(inp, weight, pairs, n_rows, transpose, flip):
     ws = _workspace(inp.device, lib.bfhip_spconv_workspace_bytes(kv, cin, cout), "gemm")
     with torch.cuda.device(inp.device):
         rc = lib.bfhip_spconv_gemm(_lib.ptr(inp), _lib.ptr(weight), _lib.ptr(pairs), pairs.shape[1], kv, n_rows, cin,
-                                   cout, 1 if transpose else 0, 1 if flip else 0, _lib.ptr(out), _lib.ptr(ws),
-                                   ws.numel(), _lib.stream_of(inp))
+                                   cout, 1 if transpose else 0, 1 if flip else 0, _lib.ptr(perm), _lib.ptr(row_mask),
+                                   _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_of(inp))
     _lib.check(rc, "spconv_gemm")
     return out
 
@@ -119,7 +139,7 @@ class _SparseConvFunction(torch.autograd.Function):
     def forward(ctx, features, weight, data, n_in):
         features = features.contiguous().float()
         w = weight.contiguous().float()
-        out = _gemm(features, w, data.pair_fwd, data.pair_fwd.shape[1], False, False)
+        out = _gemm(features, w, data.pair_fwd, data.pair_fwd.shape[1], False, False, data.perm_fwd, data.mask_fwd)
         ctx.save_for_backward(features, w)
         ctx.data = data
         ctx.n_in = n_in
@@ -133,9 +153,11 @@ class _SparseConvFunction(torch.autograd.Function):
         d_feat = d_w = None
         if ctx.needs_input_grad[0]:
             if data.is_subm:
-                d_feat = _gemm(grad_out, w, data.pair_fwd, ctx.n_in, True, True)
+                # SubM: pair_fwd doubles as the backward table with flipped offsets; rows with equal masks stay
+                # adjacent under perm_fwd (the flip permutes mask bits), the per-wave masks are recomputed
+                d_feat = _gemm(grad_out, w, data.pair_fwd, ctx.n_in, True, True, data.perm_fwd, data.mask_fwd)
             else:
-                d_feat = _gemm(grad_out, w, data.pair_bwd, ctx.n_in, True, False)
+                d_feat = _gemm(grad_out, w, data.pair_bwd, ctx.n_in, True, False, data.perm_bwd, data.mask_bwd)
         if ctx.needs_input_grad[1]:
             cout, cin = w.shape[0], w.shape[-1]
             kv = data.pair_fwd.shape[0]
@@ -145,8 +167,8 @@ class _SparseConvFunction(torch.autograd.Function):
             ws = _workspace(w.device, lib.bfhip_spconv_wgrad_workspace_bytes(kv, cin, cout, n_out), "wgrad")
             with torch.cuda.device(w.device):
                 rc = lib.bfhip_spconv_wgrad(_lib.ptr(features), _lib.ptr(grad_out), _lib.ptr(data.pair_fwd), n_out, kv,
-                                            n_out, cin, cout, _lib.ptr(d_w), _lib.ptr(ws), ws.numel(),
-                                            _lib.stream_of(w))
+                                            n_out, cin, cout, _lib.ptr(data.perm_fwd), _lib.ptr(d_w), _lib.ptr(ws),
+                                            ws.numel(), _lib.stream_of(w))
             _lib.check(rc, "spconv_wgrad")
         return d_feat, d_w, None, None
 

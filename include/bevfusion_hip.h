@@ -218,13 +218,21 @@ int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *
                                const int *dilation, int n_out, int32_t *out_indices,
                                int32_t *pair_fwd, int32_t *pair_bwd, int32_t *counts_dev,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* row_mask[n] bit k = (pairs[k][n] >= 0); perm = rows stably sorted by mask, so that the 16 rows of an
+ * MFMA tile share their kernel offsets and whole offsets are skipped per tile (cf. spconv's
+ * mask_argsort, projects/SparseConvolution/sparse_functional.py:139-162).  perm/row_mask are optional
+ * (NULL) inputs of gemm / wgrad; results do not depend on them (only the fp32 summation order of wgrad). */
+size_t bfhip_rulebook_sort_rows_workspace_bytes(int n_rows, int KV);
+int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, int n_rows, uint32_t *row_mask,
+                             int32_t *perm, void *workspace, size_t workspace_bytes, void *stream);
 size_t bfhip_spconv_workspace_bytes(int KV, int Cin, int Cout);
 int bfhip_spconv_gemm(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
-                      int n_rows, int Cin, int Cout, int transpose, int flip, float *out,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      int n_rows, int Cin, int Cout, int transpose, int flip, const int32_t *perm,
+                      const uint32_t *row_mask, float *out, void *workspace, size_t workspace_bytes,
+                      void *stream);
 size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout, int n_rows);
 int bfhip_spconv_wgrad(const float *in, const float *dout, const int32_t *pairs, int ld, int KV,
-                       int n_rows, int Cin, int Cout, float *dW, void *workspace,
+                       int n_rows, int Cin, int Cout, const int32_t *perm, float *dW, void *workspace,
                        size_t workspace_bytes, void *stream);
 int bfhip_sparse_to_bev(const float *feats, const int32_t *indices, int N, int C, int B, int X,
                         int Y, int Z, float *out, void *stream);
