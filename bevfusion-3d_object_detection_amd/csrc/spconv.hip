@@ -410,31 +410,42 @@ __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__res
       if (e < NT * 64) sB[buf][e] = pre[i];
     }
   };
+  auto next_set = [&](int kk) {  // next offset the workgroup needs after kk (KV if none)
+    unsigned rest = gmask & ~((2u << kk) - 1u);
+    return rest ? __ffs(rest) - 1 : KV;
+  };
+  auto load_idx = [&](int kk, int *dst) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      dst[r] = (kk < KV && my_row[r] >= 0 && ((wmask >> kk) & 1u)) ? pairs[(size_t)kk * ld + my_row[r]] : -1;
+  };
+  auto gather = [&](const int *ix, int c, f32x4 *dst) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      dst[r] = ix[r] >= 0 ? *(const f32x4 *)(in + (size_t)ix[r] * Kdim + c * 16 + lq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  // software pipeline: weight tile i+1 (global->regs->LDS), A rows of step i+1 and the pair indices of
+  // the NEXT offset are all in flight while the MFMAs of step i run
   int k = gmask ? __ffs(gmask) - 1 : KV;
   int cc = 0, buf = 0;
-  if (k < KV) prefetch(k, 0);
-  int idx[R];
+  int idx[R], idx_nxt[R];
+  f32x4 a[R], a_nxt[R];
+  if (k < KV) {
+    prefetch(k, 0);
+    load_idx(k, idx);
+    load_idx(next_set(k), idx_nxt);
+    gather(idx, 0, a);
+  }
   while (k < KV) {
     stash(buf);
     __syncthreads();
-    // next step
     int nk = k, ncc = cc + 1;
-    if (ncc == CC) {
-      ncc = 0;
-      unsigned rest = gmask & ~((2u << k) - 1u);
-      nk = rest ? __ffs(rest) - 1 : KV;
+    if (ncc == CC) { ncc = 0; nk = next_set(k); }
+    if (nk < KV) {
+      prefetch(nk, ncc);
+      gather(ncc == 0 ? idx_nxt : idx, ncc, a_nxt);
     }
-    if (nk < KV) prefetch(nk, ncc);
     if ((wmask >> k) & 1u) {
-      if (cc == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) idx[r] = my_row[r] >= 0 ? pairs[(size_t)k * ld + my_row[r]] : -1;
-      }
-      f32x4 a[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        a[r] = idx[r] >= 0 ? *(const f32x4 *)(in + (size_t)idx[r] * Kdim + cc * 16 + lq * 4)
-                           : (f32x4){0.f, 0.f, 0.f, 0.f};
       f32x4 b[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) b[nt] = sB[buf][nt * 64 + lane];
@@ -446,6 +457,13 @@ __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__res
           for (int nt = 0; nt < NT; ++nt)
             acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[nt][j], acc[r][nt], 0, 0, 0);
     }
+    if (ncc == 0 && nk < KV) {  // moving on to offset nk: rotate the index registers, fetch the one after
+#pragma unroll
+      for (int r = 0; r < R; ++r) idx[r] = idx_nxt[r];
+      load_idx(next_set(nk), idx_nxt);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = a_nxt[r];
     k = nk;
     cc = ncc;
     buf ^= 1;
@@ -881,7 +899,7 @@ BFHIP_EXPORT int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, 
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(KV > 0 && KV <= 32 && n_rows >= 0 && ld >= n_rows, "rulebook_sort_rows: bad sizes");
   if (n_rows == 0) return BFHIP_OK;
-  BFHIP_REQUIRE(pairs && row_mask && perm, "rulebook_sort_rows: null pointer");
+  BFHIP_REQUIRE(pairs && row_mask, "rulebook_sort_rows: null pointer");
   if (workspace_bytes < bfhip_rulebook_sort_rows_workspace_bytes(n_rows, KV) || !workspace) { set_error("rulebook_sort_rows: workspace too small"); return BFHIP_E_WORKSPACE; }
   Workspace ws(workspace, workspace_bytes);
   unsigned *iota = ws.take<unsigned>(n_rows), *keys_out = ws.take<unsigned>(n_rows);
@@ -890,7 +908,9 @@ BFHIP_EXPORT int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, 
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
   hipLaunchKernelGGL(row_mask_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, stream, pairs, ld, KV, n_rows, row_mask, iota);
-  hipError_t e = rocprim::radix_sort_pairs(tmp, sb, row_mask, keys_out, iota, (unsigned *)perm, (size_t)n_rows, 0, KV, stream);
+  hipError_t e = hipSuccess;
+  if (perm)  // perm == NULL: masks only
+    e = rocprim::radix_sort_pairs(tmp, sb, row_mask, keys_out, iota, (unsigned *)perm, (size_t)n_rows, 0, KV, stream);
   prof_end(&ps);
   if (e != hipSuccess) { set_error("rulebook_sort_rows: sort: %s", hipGetErrorString(e)); return BFHIP_E_LAUNCH; }
   return check_launch("rulebook_sort_rows");

@@ -10,6 +10,7 @@ reference uses it: `SparseConvTensor(features, indices, spatial_shape, batch_siz
 stride=, padding=, dilation=, bias=, indice_key=); weight layout (out, k0, k1, k2, in).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -51,12 +52,16 @@ class IndiceData:
         self.mask_bwd, self.perm_bwd = sort_rows(pair_bwd) if pair_bwd is not None else (None, None)
 
 
+# mask-sorted row order for the gather-GEMM (tile-level offset skipping); masks alone are always computed
+SORT_ROWS = os.environ.get("BFHIP_SPCONV_SORT", "1") == "1"
+
+
 def sort_rows(pairs):
-    """(row_mask u32[n], perm i32[n]) of a pair table i32[KV, n] (bfhip_rulebook_sort_rows)."""
+    """(row_mask u32[n], perm i32[n] or None) of a pair table i32[KV, n] (bfhip_rulebook_sort_rows)."""
     kv, n = pairs.shape
     dev = pairs.device
     mask = torch.empty(n, dtype=torch.int32, device=dev)
-    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev) if SORT_ROWS else None
     if n == 0:
         return mask, perm
     lib = _lib.load()
@@ -167,7 +172,7 @@ class _SparseConvFunction(torch.autograd.Function):
             ws = _workspace(w.device, lib.bfhip_spconv_wgrad_workspace_bytes(kv, cin, cout, n_out), "wgrad")
             with torch.cuda.device(w.device):
                 rc = lib.bfhip_spconv_wgrad(_lib.ptr(features), _lib.ptr(grad_out), _lib.ptr(data.pair_fwd), n_out, kv,
-                                            n_out, cin, cout, _lib.ptr(data.perm_fwd), _lib.ptr(d_w), _lib.ptr(ws),
+                                            n_out, cin, cout, None, _lib.ptr(d_w), _lib.ptr(ws),
                                             ws.numel(), _lib.stream_of(w))
             _lib.check(rc, "spconv_wgrad")
         return d_feat, d_w, None, None
