@@ -164,6 +164,9 @@ class _ModelWorkload:
                 sub = getattr(self.model, name, None)  # 2-D conv stacks only (sparse conv weights are 5-D)
                 if sub is not None:
                     sub.to(memory_format=torch.channels_last)
+        if self.amp and getattr(self.model, "view_transform", None) is not None:
+            self.model.view_transform.conv_dtype = torch.bfloat16  # dense convs bf16, index paths + pooling fp32
+        torch.backends.cudnn.benchmark = True                      # MIOpen find mode for the dense convs
         self.n_params = sum(p.numel() for p in self.model.parameters())
         self.step_model = self.model
         if ddp:

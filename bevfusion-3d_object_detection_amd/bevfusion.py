@@ -61,8 +61,24 @@ class BEVFusion(nn.Module):
     def voxelize(self, points: List[torch.Tensor]):
         """(reference :227-255) per-sample hard voxelization, batch id prepended -> (b, x, y, z), mean reduce."""
         feats, coords, sizes = [], [], []
-        for k, res in enumerate(points):
-            ret = self.pts_voxel_layer(res)
+        layer = self.pts_voxel_layer
+        if layer.max_num_points != -1 and (layer.max_voxels[0] if self.training else layer.max_voxels[1]) != -1:
+            # hard voxelization: launch every sample first (sync-free C ABI), read all B counts with ONE host sync
+            # (the reference syncs per sample: voxelization_cuda.cu:369-370)
+            max_voxels = layer.max_voxels[0] if self.training else layer.max_voxels[1]
+            bufs, counts = [], torch.empty(len(points), dtype=torch.int32, device=points[0].device)
+            for k, res in enumerate(points):
+                res = res.contiguous()
+                v = res.new_zeros((max_voxels, layer.max_num_points, res.size(1)))
+                c = res.new_zeros((max_voxels, 3), dtype=torch.int)
+                n = res.new_zeros((max_voxels,), dtype=torch.int)
+                voxel_layer.hard_voxelize_async(res, v, c, n, layer.voxel_size, layer.point_cloud_range,
+                                                layer.max_num_points, max_voxels, counts[k:k + 1])
+                bufs.append((v, c, n))
+            rets = [(v[:m], c[:m], n[:m]) for (v, c, n), m in zip(bufs, counts.tolist())]
+        else:
+            rets = [layer(res) for res in points]
+        for k, ret in enumerate(rets):
             if len(ret) == 3:
                 f, c, n = ret
             else:

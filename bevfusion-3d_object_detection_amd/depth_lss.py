@@ -137,6 +137,10 @@ class BaseViewTransform(nn.Module):
         self.bx = nn.Parameter(bx, requires_grad=False)
         self.nx = nn.Parameter(nx, requires_grad=False)
         self.C = out_channels
+        # None = the reference's behaviour (whole view transform in fp32, BF/bevfusion.py:177).  torch.bfloat16 runs
+        # only the dense conv stacks (dtransform / depthnet / downsample) under autocast; geometry, ranks, the
+        # softmax output and the lift-splat pooling stay fp32 ("bf16 with fp32 index paths", BASELINE configs[3]).
+        self.conv_dtype = None
         self.frustum = self.create_frustum()
         self.D = self.frustum.shape[0]
         self.fp16_enabled = False
@@ -389,7 +393,9 @@ class DepthLSSTransform(BaseDepthTransform):
         d = d.reshape(BN, *d.shape[2:])
         x = x.reshape(BN, C, fH, fW)
         gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
-        x = self.depthnet(torch.cat([self.dtransform(d), x], dim=1))
+        with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
+            x = self.depthnet(torch.cat([self.dtransform(d), x], dim=1))
+        x = x.float()
         depth = x[:, :self.D].softmax(dim=1)
         est_depth_distr = depth.permute(0, 2, 3, 1).reshape(B, N, fH, fW, self.D)
         if self.training:
@@ -407,4 +413,6 @@ class DepthLSSTransform(BaseDepthTransform):
 
     def forward(self, *args, **kwargs):
         x, depth_loss = super().forward(*args, **kwargs)
-        return self.downsample(x), depth_loss
+        with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
+            x = self.downsample(x)
+        return x, depth_loss
