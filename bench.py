@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+MIOPEN_FIND = os.environ.get("BENCH_MIOPEN_FIND", "0") == "1"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
 
 
@@ -166,7 +167,7 @@ class _ModelWorkload:
                     sub.to(memory_format=torch.channels_last)
         if self.amp and getattr(self.model, "view_transform", None) is not None:
             self.model.view_transform.conv_dtype = torch.bfloat16  # dense convs bf16, index paths + pooling fp32
-        torch.backends.cudnn.benchmark = True                      # MIOpen find mode for the dense convs
+        torch.backends.cudnn.benchmark = MIOPEN_FIND               # MIOpen exhaustive find (minutes of warm-up on a fresh box)
         self.n_params = sum(p.numel() for p in self.model.parameters())
         self.step_model = self.model
         if ddp:
