@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
-    ap.add_argument("--workload", default="full", choices=["full", "lidar_only", "camera_only", "hotpath_v1"])
+    ap.add_argument("--workload", default="full", choices=["full", "lidar_only", "camera_only", "hotpath_v1", "dist_selftest"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --workload dist_selftest (CPU)")
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2, help="bounded CPU sample (frames)")
@@ -278,7 +279,60 @@ class FullModel(_ModelWorkload):
     name = ("full: BEVFusion camera+LiDAR (ResNet-50, LSS 6x256x704, hard voxelize 40k pts, sparse encoder, ConvFuser, "
             "SECOND/SECONDFPN, TransFusion head fwd) fwd + surrogate loss + bwd + clip + AdamW, bf16 autocast, fp32 index paths")
 
-WORKLOADS = {"full": FullModel, "lidar_only": LidarOnly, "camera_only": CameraOnly, "hotpath_v1": HotPathV1}
+class DistSelfTest:
+    """CPU + gloo rehearsal of the multi-rank plumbing (tests/test_distributed_cpu.py): the dense BEV tail of the
+    model (ConvFuser -> SECOND -> SECONDFPN -> head convs, reduced size) under DDP, one batch per rank, no data-path
+    collective.  The hand-written HIP ops have no CPU path and are not part of this workload."""
+
+    name = "dist_selftest: reduced ConvFuser+SECOND+SECONDFPN under DDP on CPU (gloo), plumbing rehearsal only"
+    amp = False
+
+    def __init__(self, device, batch, points, seed_base=0, ddp=False, local_rank=0):
+        import bevfusion_amd  # noqa: F401
+        from bevfusion_amd import dense_modules as dm
+        torch.manual_seed(0)
+        self.B = batch
+        self.nk = self.m = None
+        self.model = torch.nn.Sequential()
+        self.fuser = dm.ConvFuser([8, 16], 16)
+        self.backbone = dm.SECOND(16, [16, 32], [1, 1], [1, 2])
+        self.neck = dm.SECONDFPN([16, 32], [16, 16], [1, 2], use_conv_for_no_stride=True)
+        self.net = torch.nn.ModuleList([self.fuser, self.backbone, self.neck])
+        self.n_params = sum(p.numel() for p in self.net.parameters())
+
+        class Tail(torch.nn.Module):
+            def __init__(s, fuser, backbone, neck):
+                super().__init__()
+                s.fuser, s.backbone, s.neck = fuser, backbone, neck
+
+            def forward(s, a, b):
+                return s.neck(s.backbone(s.fuser([a, b])))[0]
+
+        self.tail = Tail(self.fuser, self.backbone, self.neck)
+        self.step_model = self.tail
+        if ddp:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            self.step_model = DDP(self.tail)
+        self.opt = torch.optim.AdamW(self.tail.parameters(), lr=2e-4)
+        g = torch.Generator().manual_seed(seed_base)
+        self.a = torch.randn(batch, 8, 24, 24, generator=g)
+        self.b = torch.randn(batch, 16, 24, 24, generator=g)
+
+    def step(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.step_model(self.a, self.b).abs().mean()
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def collect_work(self):
+        return {}
+
+    def grad_fingerprint(self):
+        return float(sum(p.grad.double().abs().sum() for p in self.tail.parameters() if p.grad is not None))
+
+
+WORKLOADS = {"dist_selftest": DistSelfTest, "full": FullModel, "lidar_only": LidarOnly, "camera_only": CameraOnly, "hotpath_v1": HotPathV1}
 
 
 def main():
@@ -286,19 +340,29 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    cpu_mode = args.workload == "dist_selftest"
+    if not cpu_mode and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if cpu_mode:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if cpu_mode:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
 
     from bevfusion_amd import _lib
     cls = WORKLOADS[args.workload]
-    if issubclass(cls, _ModelWorkload):
+    if cpu_mode:
+        wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=world > 1, local_rank=local_rank)
+        work = {}
+    elif issubclass(cls, _ModelWorkload):
         wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=world > 1, local_rank=local_rank)
         work = wl.collect_work()
     else:
@@ -308,21 +372,25 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu_mode:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         wl.step()
     barrier()
-    _lib.profile_enable(True)
-    for op in _lib.OPS:
-        _lib.profile_read(op, reset=True)
+    if not cpu_mode:
+        _lib.profile_enable(True)
+        for op in _lib.OPS:
+            _lib.profile_read(op, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
     barrier()
     dt = time.perf_counter() - t0
-    _lib.profile_enable(False)
-    prof = {op: _lib.profile_read(op, reset=True) for op in _lib.OPS}
+    prof = {}
+    if not cpu_mode:
+        _lib.profile_enable(False)
+        prof = {op: _lib.profile_read(op, reset=True) for op in _lib.OPS}
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -366,10 +434,16 @@ def main():
         }
         if hasattr(wl, "n_params"):
             line["config"]["trainable_params"] = wl.n_params
-        if world == 1 and not args.no_cpu_baseline:
+        if cpu_mode:
+            line["data"] = "synthetic (CPU plumbing rehearsal, not a performance number)"
+            line["config"]["grad_fingerprint"] = wl.grad_fingerprint()
+        if world == 1 and not args.no_cpu_baseline and not cpu_mode:
             v, sample = wl.cpu_baseline(args.cpu_frames)
             line["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample}
         print(json.dumps(line), flush=True)
+    if cpu_mode and os.environ.get("BENCH_FINGERPRINT_DIR"):  # every rank: DDP must leave identical gradients
+        with open(os.path.join(os.environ["BENCH_FINGERPRINT_DIR"], "rank%d.txt" % rank), "w") as fh:
+            fh.write(repr(wl.grad_fingerprint()))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,53 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py (env rendezvous on 127.0.0.1, DDP gradient all-reduce, barrier,
+MAX-over-ranks timing, single JSON line from rank 0).  The HIP ops have no CPU path, so the rehearsal workload is the
+dense BEV tail only; what is tested is the distributed plumbing the GPU run shares."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(nproc, tmp_path, extra=()):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FINGERPRINT_DIR=str(tmp_path), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
+           "--workload", "dist_selftest", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "2", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line from rank 0, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_two_ranks_gloo(tmp_path):
+    out = _run(2, tmp_path)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["config"]["global_batch"] == 4 and out["config"]["frames_per_gpu_per_step"] == 2
+    # value = frames of ALL ranks / max-over-ranks time
+    assert abs(out["value"] - 2 * 2 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3
+    # DDP: both ranks hold the same (averaged) gradients although they saw different batches
+    fps = [float(open(os.path.join(tmp_path, "rank%d.txt" % r)).read()) for r in range(2)]
+    assert fps[0] > 0 and abs(fps[0] - fps[1]) <= 1e-9 * abs(fps[0])
+
+
+def test_single_rank_json_contract(tmp_path):
+    env = dict(os.environ, BENCH_FINGERPRINT_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "dist_selftest", "--backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--batch", "2"], capture_output=True, text=True, env=env,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["vs_baseline"] is None
