@@ -411,6 +411,13 @@ def main():
                for op, (ms, cnt) in prof.items() if cnt}
         # dominant hand-written op of the step = the one with the largest accumulated event time
         dom = max((op for op in work if prof.get(op, (0, 0))[1]), key=lambda o: prof[o][0], default=None)
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value is the
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement committed under profiles/ (same batch-4 sizes)
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        except (OSError, KeyError, ValueError):
+            pass
         roof = None
         if dom is not None:
             ms, cnt = prof[dom]
@@ -418,8 +425,9 @@ def main():
             sec_per_step = ms * 1e-3 / args.steps
             if w["bound"] == "hbm":
                 ach = w["bytes"] / sec_per_step / 1e9
+                traffic = int(pmc[dom]["hbm_bytes"]) if (dom in pmc and args.batch == 4) else None
                 roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_step": int(w["bytes"]),
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_step": int(w["bytes"]),
                         "ms_per_step": round(ms / args.steps, 5), "launches_per_step": cnt / args.steps}
             else:
                 ach = w["flops"] / sec_per_step / 1e12
