@@ -54,6 +54,10 @@ SIGNATURES = {
     "bfhip_dynamic_scatter_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "bfhip_dynamic_scatter_bwd": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_voxel_mean": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "bfhip_rasterise_depth_workspace_bytes": (_c_sz, [_c_int] * 3),
+    "bfhip_rasterise_depth": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 4 + [_c_int] * 3 + [_c_vp, _c_vp] + [_c_int] * 3 +
+                              [_c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_depth_histogram": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_vp, _c_vp]),
 }
 
 _lib = None

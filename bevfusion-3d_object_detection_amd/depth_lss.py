@@ -301,44 +301,71 @@ def _make_downsample(out_channels, downsample):
 class BaseDepthTransform(BaseViewTransform):
     """(reference :342-551) adds the sparse LiDAR depth image as an input of get_cam_feats."""
 
-    def rasterise_depth(self, img, points, lidar2image, img_aug_matrix, lidar_aug_matrix, lidar_aug_matrix_inverse=None):
-        """LiDAR points -> sparse depth images [B, N, 1, iH, iW] (reference :363-449).  Points are not
-        modified (the reference mutates its argument in place).  Duplicate pixels
-        keep one of the colliding depths (unspecified which, as in the reference :410-417)."""
+    def rasterise_depth(self, img, points, lidar2image, img_aug_matrix, lidar_aug_matrix, lidar_aug_matrix_inverse=None,
+                        with_histogram=False):
+        """LiDAR points -> sparse depth images [B, N, 1, iH, iW] (reference :363-449), one HIP launch pair per
+        sample (csrc/raster.hip).  Points are not modified (the reference mutates its argument in place, SURVEY
+        appendix 10).  A pixel hit by several points keeps the last one (unspecified in the reference, :410-417).
+        with_histogram: also return the un-normalised GT depth-bin counts [B, N, fH, fW, D] of :636-670,
+        accumulated in the same pass."""
         if lidar_aug_matrix_inverse is None:
             lidar_aug_matrix_inverse = torch.inverse(lidar_aug_matrix)
         B = len(points)
         N = img.shape[1]
         iH, iW = self.image_size
-        depth = torch.zeros(B, N, 1, iH, iW, device=points[0].device, dtype=torch.float32)
-        for b in range(B):
-            cur = points[b][:, :3] - lidar_aug_matrix[b, :3, 3]
-            cur = lidar_aug_matrix_inverse[b, :3, :3].matmul(cur.transpose(1, 0))
-            cur = lidar2image[b, :, :3, :3].matmul(cur) + lidar2image[b, :, :3, 3].reshape(-1, 3, 1)
-            dist = cur[:, 2, :]
-            z = torch.clamp(dist, 1e-5, 1e5)
-            cur = torch.cat((cur[:, :2, :] / z.unsqueeze(1), z.unsqueeze(1)), 1)
-            cur = img_aug_matrix[b, :, :3, :3].matmul(cur) + img_aug_matrix[b, :, :3, 3].reshape(-1, 3, 1)
-            rc = cur[:, :2, :].transpose(1, 2)[..., [1, 0]]  # (row, col)
-            on_img = (rc[..., 0] < iH) & (rc[..., 0] >= 0) & (rc[..., 1] < iW) & (rc[..., 1] >= 0)
-            rcl = rc.long()
-            flat = (torch.arange(N, device=rc.device).view(N, 1) * (iH * iW) + rcl[..., 0] * iW + rcl[..., 1])
-            flat = torch.where(on_img, flat, torch.full_like(flat, N * iH * iW))  # dump slot for misses
-            upd = torch.zeros(N * iH * iW + 1, device=rc.device, dtype=torch.float32)
-            upd.scatter_(0, flat.reshape(-1), dist.reshape(-1))
-            depth[b] = upd[:-1].view(N, 1, iH, iW)
-        return depth
+        fH, fW = self.feature_size
+        dev = points[0].device
+        depth = torch.empty(B, N, 1, iH, iW, device=dev, dtype=torch.float32)
+        counts = torch.zeros(B, N, fH, fW, self.D, device=dev, dtype=torch.float32) if with_histogram else None
+        inv_rot = lidar_aug_matrix_inverse[:, :3, :3].contiguous().float()
+        aug_t = lidar_aug_matrix[:, :3, 3].contiguous().float()
+        l2i = lidar2image.contiguous().float()
+        ia = img_aug_matrix.contiguous().float()
+        lib = _lib.load()
+        nbytes = lib.bfhip_rasterise_depth_workspace_bytes(N, iH, iW)
+        if getattr(self, "_raster_ws", None) is None or self._raster_ws.numel() < nbytes or self._raster_ws.device != dev:
+            self._raster_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dbound = _lib.host_f32(self.dbound)
+        with torch.cuda.device(dev):
+            stream = _lib.stream_of(depth)
+            for b in range(B):
+                p = points[b].contiguous().float()
+                rc = lib.bfhip_rasterise_depth(_lib.ptr(p), p.shape[0], p.shape[1], _lib.ptr(inv_rot[b]), _lib.ptr(aug_t[b]),
+                                               _lib.ptr(l2i[b]), _lib.ptr(ia[b]), N, iH, iW, _lib.ptr(depth[b]),
+                                               _lib.ptr(counts[b]) if with_histogram else None, fH, fW, self.D, dbound,
+                                               _lib.ptr(self._raster_ws), self._raster_ws.numel(), stream)
+                _lib.check(rc, "rasterise_depth")
+        return (depth, counts) if with_histogram else depth
+
+    def depth_distribution(self, counts=None, depth=None):
+        """GT depth distribution (reference :636-686): from pre-accumulated `counts` [B,N,fH,fW,D] or from a depth
+        image [BN,1,iH,iW].  Returns (gt_depth_distr, counts_3d) with bin 0 cleared."""
+        iH, iW = self.image_size
+        fH, fW = self.feature_size
+        if counts is None:
+            BN = depth.shape[0]
+            counts = torch.empty(BN, fH, fW, self.D, device=depth.device, dtype=torch.float32)
+            depth = depth.contiguous().float()
+        else:
+            BN = counts.shape[0] * counts.shape[1]
+        distr = torch.empty_like(counts)
+        with torch.cuda.device(counts.device):
+            rc = _lib.load().bfhip_depth_histogram(_lib.ptr(depth) if depth is not None else None, BN, iH, iW, fH, fW, self.D,
+                                                   _lib.host_f32(self.dbound), _lib.ptr(counts), _lib.ptr(distr),
+                                                   _lib.stream_of(counts))
+        _lib.check(rc, "depth_histogram")
+        return distr, counts
 
     def forward(self, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix,
                 metas=None, camera_intrinsics_inverse=None, img_aug_matrix_inverse=None,
                 lidar_aug_matrix_inverse=None, geom_feats_precomputed=None):
-        depth_img = self.rasterise_depth(img, points, lidar2image, img_aug_matrix, lidar_aug_matrix,
-                                         lidar_aug_matrix_inverse)
+        depth_img, counts = self.rasterise_depth(img, points, lidar2image, img_aug_matrix, lidar_aug_matrix,
+                                                 lidar_aug_matrix_inverse, with_histogram=True)
         if isinstance(geom_feats_precomputed, BevPlan):
             plan = geom_feats_precomputed
         else:
             plan = self.make_plan(**self._calibration(cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix))
-        depth, feat, est_depth_distr, gt_depth_distr, counts_3d = self.get_depth_and_feat(img, depth_img)
+        depth, feat, est_depth_distr, gt_depth_distr, counts_3d = self.get_depth_and_feat(img, depth_img, counts)
         x = self.lift_splat_bev(depth, feat, plan)
         if self.training:
             # depth cross-entropy on cells that hold LiDAR returns (reference :540-547)
@@ -370,29 +397,20 @@ class DepthLSSTransform(BaseDepthTransform):
         self.downsample = _make_downsample(out_channels, downsample)
 
     def gt_depth_distribution(self, d, B, N):
-        """Histogram of the sparse depth image over (feature cell, depth bin) (reference :636-686)."""
-        BN = B * N
-        h, w = self.image_size
+        """Histogram of the sparse depth image over (feature cell, depth bin) (reference :636-686); d [BN,1,iH,iW]."""
+        distr, counts = self.depth_distribution(depth=d)
         fH, fW = self.feature_size
-        dev = d.device
-        rows = torch.arange(h, device=dev).view(1, -1, 1) // (h // fH)
-        cols = torch.arange(w, device=dev).view(1, 1, -1) // (w // fW)
-        cam = torch.arange(BN, device=dev).view(-1, 1, 1)
-        cell_id = (cam * fH * fW + rows * fW + cols).view(-1)
-        lo, hi, step = self.dbound
-        bins = ((d.clamp(min=lo, max=hi - 0.5 * step) + 0.5 * step - lo) / step).long().view(-1)
-        counts = torch.zeros(BN * fH * fW * self.D, dtype=torch.float, device=dev)
-        counts.scatter_add_(0, cell_id * self.D + bins, torch.ones_like(bins, dtype=torch.float))
-        counts_3d = counts.view(B, N, fH, fW, self.D)
-        counts_3d[..., 0] = 0.0
-        return counts_3d / (counts_3d.sum(dim=-1, keepdim=True) + 1e-8), counts_3d
+        return distr.view(B, N, fH, fW, self.D), counts.view(B, N, fH, fW, self.D)
 
-    def get_depth_and_feat(self, x, d):
+    def get_depth_and_feat(self, x, d, counts=None):
         B, N, C, fH, fW = x.shape
         BN = B * N
         d = d.reshape(BN, *d.shape[2:])
         x = x.reshape(BN, C, fH, fW)
-        gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
+        if counts is not None:  # accumulated by the rasteriser in the same pass
+            gt_depth_distr, counts_3d = self.depth_distribution(counts=counts)
+        else:
+            gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
         with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
             x = self.depthnet(torch.cat([self.dtransform(d), x], dim=1))
         x = x.float()

@@ -239,6 +239,24 @@ int bfhip_sparse_to_bev(const float *feats, const int32_t *indices, int N, int C
 int bfhip_bev_to_sparse(const float *grad_out, const int32_t *indices, int N, int C, int B, int X,
                         int Y, int Z, float *grad_feats, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * sparse LiDAR depth images + GT depth histogram  (replaces the per-sample torch loop of
+ *   BaseDepthTransform.forward, BF/depth_lss.py:372-449, and the scatter_add_ histogram of
+ *   DepthLSSTransform.get_cam_feats, :636-686)
+ *   points f32[n,f]; inv_rot f32[9] = lidar_aug_matrix_inverse[:3,:3]; aug_trans f32[3] = lidar_aug_matrix[:3,3];
+ *   lidar2image, img_aug f32[ncam,16] (row-major 4x4).  depth f32[ncam,iH,iW] is fully written.
+ *   A pixel hit by several points keeps the LAST point (torch's scatter_ leaves it unspecified, :410-417).
+ *   counts (optional, f32[ncam,fH,fW,D], cleared by the caller) receives the depth-bin histogram of the hit
+ *   pixels; bfhip_depth_histogram normalises it (bin 0 excluded, as :670-674) or rebuilds it from a depth image.
+ * --------------------------------------------------------------------------------------- */
+size_t bfhip_rasterise_depth_workspace_bytes(int ncam, int iH, int iW);
+int bfhip_rasterise_depth(const float *points, int n, int f, const float *inv_rot, const float *aug_trans,
+                          const float *lidar2image, const float *img_aug, int ncam, int iH, int iW,
+                          float *depth, float *counts, int fH, int fW, int D, const float *dbound_host,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int bfhip_depth_histogram(const float *depth, int BN, int iH, int iW, int fH, int fW, int D,
+                          const float *dbound_host, float *counts, float *distr, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

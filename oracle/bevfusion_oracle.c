@@ -449,7 +449,7 @@ ORACLE_API void oracle_bev_cells(const float *geom, int64_t nprime, int B, const
  * frustum f32[D*HW,3]; per camera (B*N): post_trans[3], post_rots_inv[9], combine[9], c2l_trans[3];
  * per sample (B): extra_rots[9], extra_trans[3].  out f32[B*N*D*HW, 3].
  * ------------------------------------------------------------------------------------------ */
-static inline void mat3_vec(const float *m, const float *p, float *o) {
+static inline void mat3_vec(const float *m, const float *p, float *o) { /* defined before first use below */
   for (int i = 0; i < 3; ++i) {
     float a = m[i * 3 + 0] * p[0];
     float b = m[i * 3 + 1] * p[1];
@@ -479,4 +479,74 @@ ORACLE_API void oracle_frustum_geometry(const float *frustum, int B, int N, int 
         o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
       }
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse depth rasteriser: BF/depth_lss.py:372-449 (BaseDepthTransform.forward, per-sample loop).
+ *   cur = pts[:, :3] - lidar_aug[:3,3]                         (:381)
+ *   cur = lidar_aug_inv[:3,:3] @ cur                           (:382)
+ *   cur = lidar2image[:, :3,:3] @ cur + lidar2image[:, :3,3]   (:385-386)
+ *   dist = cur.z ; cur.z = clamp(cur.z, 1e-5, 1e5) ; cur.xy /= cur.z         (:389-391)
+ *   cur = img_aug[:, :3,:3] @ cur + img_aug[:, :3,3]           (:394-395)
+ *   (row, col) = (cur.y, cur.x) ; on_img = 0 <= row < iH and 0 <= col < iW   (:400-407)
+ *   depth[cam, long(row), long(col)] = dist                    (:433-446, scatter_)
+ * Duplicate pixels: torch's scatter_ leaves it unspecified which point wins (author's note :410-417);
+ * on the CPU it is the last point in index order, which is the rule fixed here and in the HIP kernel.
+ * 3x3 products use the fixed association ((m0*p0 + m1*p1) + m2*p2) like oracle_frustum_geometry.
+ * inv_rot f32[9], aug_trans f32[3] (per sample); l2i f32[ncam,16], img_aug f32[ncam,16] (row-major 4x4).
+ * depth f32[ncam, iH, iW], zero-filled here.
+ * ------------------------------------------------------------------------------------------ */
+ORACLE_API void oracle_rasterise_depth(const float *points, int n, int f, const float *inv_rot,
+                                       const float *aug_trans, const float *l2i, const float *img_aug,
+                                       int ncam, int iH, int iW, float *depth) {
+  memset(depth, 0, sizeof(float) * (size_t)ncam * iH * iW);
+  for (int c = 0; c < ncam; ++c) {
+    const float *L = l2i + c * 16, *A = img_aug + c * 16;
+    float Lr[9] = {L[0], L[1], L[2], L[4], L[5], L[6], L[8], L[9], L[10]};
+    float Ar[9] = {A[0], A[1], A[2], A[4], A[5], A[6], A[8], A[9], A[10]};
+    for (int i = 0; i < n; ++i) {
+      float p[3], q[3];
+      for (int k = 0; k < 3; ++k) p[k] = points[(size_t)i * f + k] - aug_trans[k];
+      mat3_vec(inv_rot, p, q);
+      mat3_vec(Lr, q, p);
+      p[0] = p[0] + L[3]; p[1] = p[1] + L[7]; p[2] = p[2] + L[11];
+      float dist = p[2];
+      float z = dist < 1e-5f ? 1e-5f : (dist > 1e5f ? 1e5f : dist);
+      if (!(dist == dist)) z = dist; /* NaN stays NaN like torch.clamp */
+      p[0] = p[0] / z; p[1] = p[1] / z; p[2] = z;
+      mat3_vec(Ar, p, q);
+      float col = q[0] + A[3], row = q[1] + A[7];
+      if (!(row < (float)iH && row >= 0.f && col < (float)iW && col >= 0.f)) continue;
+      depth[((size_t)c * iH + (int)row) * iW + (int)col] = dist;
+    }
+  }
+}
+
+/* GT depth histogram: BF/depth_lss.py:636-686 (get_cam_feats, `if self.training or True` branch).
+ *   bin = long((clamp(d, lo, hi - 0.5*step) + 0.5*step - lo) / step)         (:653-658)
+ *   counts[cam, row // (h // fH), col // (w // fW), bin] += 1                (:646-668)
+ *   counts[..., 0] = 0 ; distr = counts / (counts.sum(-1) + 1e-8)             (:670-674)
+ * depth f32[BN, h, w]; counts / distr f32[BN, fH, fW, D]. */
+ORACLE_API void oracle_depth_histogram(const float *depth, int BN, int h, int w, int fH, int fW, int D,
+                                       float lo, float hi, float step, float *counts, float *distr) {
+  size_t total = (size_t)BN * fH * fW * D;
+  memset(counts, 0, sizeof(float) * total);
+  float half = (float)(0.5 * (double)step);
+  float cmax = (float)((double)hi - 0.5 * (double)step);
+  int rh = h / fH, rw = w / fW;
+  for (int c = 0; c < BN; ++c)
+    for (int r = 0; r < h; ++r)
+      for (int q = 0; q < w; ++q) {
+        float d = depth[((size_t)c * h + r) * w + q];
+        float cl = d < lo ? lo : (d > cmax ? cmax : d);
+        int bin = (int)(((cl + half) - lo) / step);
+        size_t cell = ((size_t)c * fH + r / rh) * fW + q / rw;
+        counts[cell * D + bin] += 1.0f;
+      }
+  for (size_t cell = 0; cell < (size_t)BN * fH * fW; ++cell) {
+    counts[cell * D] = 0.f;
+    float s = 0.f;
+    for (int b = 0; b < D; ++b) s += counts[cell * D + b];
+    for (int b = 0; b < D; ++b) distr[cell * D + b] = counts[cell * D + b] / (s + 1e-8f);
+  }
 }

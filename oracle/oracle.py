@@ -279,3 +279,26 @@ def sparse_to_bev(feats, indices, B, X, Y, Z):
     out = np.empty((B, c * Z, X, Y), np.float32)
     lib().oracle_sparse_to_bev(_p(feats), _p(indices), n, c, B, X, Y, Z, _p(out))
     return out
+
+
+# ------------------------------------------------------------------ sparse depth rasteriser + GT histogram
+def rasterise_depth(points, inv_rot, aug_trans, lidar2image, img_aug, iH, iW):
+    """points f32[n,F]; inv_rot f32[3,3]; aug_trans f32[3]; lidar2image, img_aug f32[ncam,4,4] -> depth f32[ncam,iH,iW]."""
+    points = _f32(points)
+    l2i, ia = _f32(lidar2image), _f32(img_aug)
+    ncam = l2i.shape[0]
+    out = np.empty((ncam, iH, iW), np.float32)
+    lib().oracle_rasterise_depth(_p(points), points.shape[0], points.shape[1], _p(_f32(inv_rot)), _p(_f32(aug_trans)),
+                                 _p(l2i), _p(ia), ncam, int(iH), int(iW), _p(out))
+    return out
+
+
+def depth_histogram(depth, fH, fW, D, dbound):
+    """depth f32[BN,h,w] -> (counts, distr) f32[BN,fH,fW,D]."""
+    depth = _f32(depth)
+    BN, h, w = depth.shape
+    counts = np.empty((BN, fH, fW, D), np.float32)
+    distr = np.empty((BN, fH, fW, D), np.float32)
+    lib().oracle_depth_histogram(_p(depth), BN, h, w, int(fH), int(fW), int(D), ctypes.c_float(dbound[0]),
+                                 ctypes.c_float(dbound[1]), ctypes.c_float(dbound[2]), _p(counts), _p(distr))
+    return counts, distr

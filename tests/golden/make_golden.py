@@ -190,6 +190,44 @@ def make_lss_goldens():
                full_counts=np.array([kept.numel(), int(kept.sum()), len(starts), int(lengths.max()),
                                      int(np.median(lengths))], np.int64),
                full_dx=vt.dx.detach().numpy(), full_bx=vt.bx.detach().numpy(), full_nx=vt.nx.detach().numpy())
+    # B3: the reference's sparse-depth rasteriser (BaseDepthTransform.forward :372-449) and GT depth histogram
+    # (DepthLSSTransform.get_cam_feats :636-686), tiny rig, 2 samples.  The rasteriser lives inside forward(); the
+    # depth images are captured at its call of get_cam_feats.
+    dcfg = dict(tiny, in_channels=16, out_channels=8)
+    dvt = mod.DepthLSSTransform(**dcfg)
+    dvt.eval()
+    rig = synthetic.camera_rig(batch=2, seed=5, train_aug=True)
+    rig["img_aug_matrix"][..., 0, 0] = 0.12
+    rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3] = -8.0
+    rig["img_aug_matrix"][..., 1, 3] = -44.0
+    t = {k: torch.from_numpy(v) for k, v in rig.items()}
+    pts = [torch.from_numpy(synthetic.lidar_sweep(6000, seed=300 + i)[:, :5].copy()) for i in range(2)]
+    captured = {}
+
+    class _Stop(Exception):
+        pass
+
+    real_get_cam_feats = dvt.get_cam_feats
+
+    def capture(img, depth):
+        captured["depth"] = depth.clone()
+        raise _Stop()
+
+    dvt.get_cam_feats = capture
+    img = torch.zeros(2, 6, 16, 8, 22)
+    try:
+        with torch.no_grad():
+            dvt(img, [p.clone() for p in pts], t["lidar2image"], t["camera_intrinsics"], t["camera2lidar"],
+                t["img_aug_matrix"], t["lidar_aug_matrix"], None, None, None, None, None)
+    except _Stop:
+        pass
+    with torch.no_grad():
+        _, est, gt_distr, counts3d = real_get_cam_feats(img, captured["depth"])
+    out.update(rast_depth=captured["depth"].numpy(), rast_gt_distr=gt_distr.numpy(), rast_counts=counts3d.numpy(),
+               rast_points_sha=sha(np.stack([p.numpy() for p in pts])))
+    for k, v in rig.items():
+        out["rast_rig_" + k] = v
     np.savez_compressed(os.path.join(HERE, "lss_ref.npz"), **out)
     print("lss_ref.npz: counts (N', kept, intervals, max len, median len) =", out["full_counts"])
 
