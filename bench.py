@@ -181,7 +181,8 @@ class _ModelWorkload:
         self.step_model = self.model
         if ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
-            self.step_model = DDP(self.model, device_ids=[local_rank], gradient_as_bucket_view=True)
+            # BatchNorm statistics stay local (no SyncBN in the reference configs): buffers are not broadcast
+            self.step_model = DDP(self.model, device_ids=[local_rank], gradient_as_bucket_view=True, broadcast_buffers=False)
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=2e-4, weight_decay=0.01, fused=True)
         self.loss_fn = surrogate_loss
         self.inputs = {}

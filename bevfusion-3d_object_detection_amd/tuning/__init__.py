@@ -17,7 +17,8 @@ def use_shipped_miopen_db():
     if os.environ.get("MIOPEN_USER_DB_PATH") or os.environ.get("BFHIP_NO_SHIPPED_MIOPEN_DB") == "1":
         return os.environ.get("MIOPEN_USER_DB_PATH")
     src = os.path.join(_HERE, "miopen_userdb")
-    dst = os.path.join(tempfile.gettempdir(), "bfhip_miopen_userdb_%d" % os.getuid())
+    # one writable copy per local rank: ranks of one node must not share MIOpen's db files
+    dst = os.path.join(tempfile.gettempdir(), "bfhip_miopen_userdb_%d_r%s" % (os.getuid(), os.environ.get("LOCAL_RANK", "0")))
     try:
         os.makedirs(dst, exist_ok=True)
         for f in os.listdir(src):
