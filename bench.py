@@ -358,8 +358,12 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_ddp = os.environ.get("BENCH_FORCE_DDP", "0") == "1"  # rehearse the DDP wrapper with a 1-rank group
+    if world > 1 or force_ddp:
         import torch.distributed as dist
+        if force_ddp and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"), RANK="0",
+                              WORLD_SIZE="1", LOCAL_RANK="0")
         if cpu_mode:
             dist.init_process_group("gloo")
         else:
@@ -372,7 +376,7 @@ def main():
         wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=world > 1, local_rank=local_rank)
         work = {}
     elif issubclass(cls, _ModelWorkload):
-        wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=world > 1, local_rank=local_rank)
+        wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=world > 1 or force_ddp, local_rank=local_rank)
         work = wl.collect_work()
     else:
         wl = cls(dev, args.batch, args.points, seed_base=100 * rank)
