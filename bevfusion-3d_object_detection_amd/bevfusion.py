@@ -99,11 +99,13 @@ class BEVFusion(nn.Module):
 
     def extract_pts_feat(self, batch_inputs_dict) -> torch.Tensor:
         points = batch_inputs_dict["points"]
-        with torch.autocast("cuda", enabled=False):
+        with torch.autocast("cuda", enabled=False):  # fp32 island = voxelization only, as the reference (:201-206)
             points = [p.float() for p in points]
             feats, coords, sizes = self.voxelize(points)
             batch_size = len(points)  # the reference reads coords[-1, 0] + 1 from the device (:206)
-            return self.pts_middle_encoder(feats, coords, batch_size)
+        # the encoder runs under the caller's autocast (the reference's spconv layers run in half precision under AMP);
+        # here: bf16-input MFMA with fp32 accumulation, fp32 features / BatchNorm / index paths
+        return self.pts_middle_encoder(feats, coords, batch_size)
 
     # ------------------------------------------------------------------ camera branch
     def extract_img_feat(self, x, points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,

@@ -484,6 +484,186 @@ __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__res
     }
 }
 
+// ---- bf16-input variant (fp32 features in HBM, converted on load; fp32 accumulate): for the bf16 configs.
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[row = l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4) + j][col = l&15], j < 8,
+// so one step covers 32 input channels (two float4 gathers per lane and row tile) with ONE MFMA per tile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Wp16[((k*CC32 + c32)*NT + nt)*64 + lane][j] = bf16(M_k[c32*32 + 8*(lane>>4) + j][nt*16 + (lane&15)])
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__restrict__ W, int Cout,
+                                                                int KV, int Cin, int transpose, int flip,
+                                                                int CC32, int NT, __bf16 *__restrict__ Wp) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)KV * CC32 * NT * 64 * 8;
+  if (t >= total) return;
+  int j = (int)(t & 7);
+  int lane = (int)((t >> 3) & 63);
+  long long r = t >> 9;
+  int nt = (int)(r % NT); r /= NT;
+  int c32 = (int)(r % CC32);
+  int k = (int)(r / CC32);
+  int kk = c32 * 32 + 8 * (lane >> 4) + j;
+  int nn = nt * 16 + (lane & 15);
+  float v = 0.f;
+  if (!transpose) {
+    if (kk < Cin && nn < Cout) v = W[((size_t)nn * KV + k) * Cin + kk];
+  } else {
+    int ks = flip ? KV - 1 - k : k;
+    if (kk < Cout && nn < Cin) v = W[((size_t)kk * KV + ks) * Cin + nn];
+  }
+  Wp[t] = (__bf16)v;
+}
+
+template <int NT, int R>
+__global__ __launch_bounds__(256) void spconv_gemm_bf16_kernel(const float *__restrict__ in, int Kdim,
+                                                               const bf16x8 *__restrict__ Wp,
+                                                               const int *__restrict__ pairs, int ld,
+                                                               int KV, int n_rows, int Ndim,
+                                                               const int *__restrict__ perm,
+                                                               const unsigned *__restrict__ row_mask,
+                                                               float *__restrict__ out) {
+  __shared__ bf16x8 sB[2][NT * 64];
+  __shared__ unsigned s_mask;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const long long row_base = ((long long)blockIdx.x * 4 + wv) * (R * 16);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int CC = (Kdim + 31) >> 5;
+  if (tid == 0) s_mask = 0u;
+  __syncthreads();
+  int my_row[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    long long sp = row_base + r * 16 + lr;
+    my_row[r] = sp < n_rows ? (perm ? perm[sp] : (int)sp) : -1;
+  }
+  unsigned wmask = 0u;
+  if (row_mask) {
+    unsigned mm = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) mm |= my_row[r] >= 0 ? row_mask[my_row[r]] : 0u;
+    for (int o = 32; o > 0; o >>= 1) mm |= __shfl_xor(mm, o);
+    wmask = mm;
+  } else {
+    for (int k = 0; k < KV; ++k) {
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) any |= (my_row[r] >= 0) && (pairs[(size_t)k * ld + my_row[r]] >= 0);
+      if (__any(any)) wmask |= 1u << k;
+    }
+  }
+  if (lane == 0 && wmask) atomicOr(&s_mask, wmask);
+  __syncthreads();
+  unsigned gmask = s_mask;
+
+  f32x4 acc[R][NT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int LOADS = (NT * 64 + 255) / 256;
+  bf16x8 pre[LOADS];
+  auto prefetch = [&](int k, int cc) {
+    const bf16x8 *wp = Wp + ((size_t)(k * CC + cc) * NT) * 64;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int e = tid + i * 256;
+      if (e < NT * 64) pre[i] = wp[e];
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int e = tid + i * 256;
+      if (e < NT * 64) sB[buf][e] = pre[i];
+    }
+  };
+  auto next_set = [&](int kk) {
+    unsigned rest = gmask & ~((2u << kk) - 1u);
+    return rest ? __ffs(rest) - 1 : KV;
+  };
+  auto load_idx = [&](int kk, int *dst) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      dst[r] = (kk < KV && my_row[r] >= 0 && ((wmask >> kk) & 1u)) ? pairs[(size_t)kk * ld + my_row[r]] : -1;
+  };
+  const bool lane_k_ok_base = true;
+  (void)lane_k_ok_base;
+  auto gather = [&](const int *ix, int c, f32x4 *lo, f32x4 *hi) {
+    const int ch = c * 32 + lq * 8;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (ix[r] >= 0 && ch < Kdim) {
+        const float *src = in + (size_t)ix[r] * Kdim + ch;
+        lo[r] = *(const f32x4 *)src;
+        hi[r] = *(const f32x4 *)(src + 4);
+      } else {
+        lo[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        hi[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  int k = gmask ? __ffs(gmask) - 1 : KV;
+  int cc = 0, buf = 0;
+  int idx[R], idx_nxt[R];
+  f32x4 alo[R], ahi[R], nlo[R], nhi[R];
+  if (k < KV) {
+    prefetch(k, 0);
+    load_idx(k, idx);
+    load_idx(next_set(k), idx_nxt);
+    gather(idx, 0, alo, ahi);
+  }
+  while (k < KV) {
+    stash(buf);
+    __syncthreads();
+    int nk = k, ncc = cc + 1;
+    if (ncc == CC) { ncc = 0; nk = next_set(k); }
+    if (nk < KV) {
+      prefetch(nk, ncc);
+      gather(ncc == 0 ? idx_nxt : idx, ncc, nlo, nhi);
+    }
+    if ((wmask >> k) & 1u) {
+      bf16x8 a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        a[r][0] = (__bf16)alo[r][0]; a[r][1] = (__bf16)alo[r][1]; a[r][2] = (__bf16)alo[r][2]; a[r][3] = (__bf16)alo[r][3];
+        a[r][4] = (__bf16)ahi[r][0]; a[r][5] = (__bf16)ahi[r][1]; a[r][6] = (__bf16)ahi[r][2]; a[r][7] = (__bf16)ahi[r][3];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bf16x8 b = sB[buf][nt * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r], b, acc[r][nt], 0, 0, 0);
+      }
+    }
+    if (ncc == 0 && nk < KV) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) idx[r] = idx_nxt[r];
+      load_idx(next_set(nk), idx_nxt);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { alo[r] = nlo[r]; ahi[r] = nhi[r]; }
+    k = nk;
+    cc = ncc;
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = __shfl(my_row[r], lq * 4 + i);
+      if (row >= 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          int col = nt * 16 + lr;
+          if (col < Ndim) out[(size_t)row * Ndim + col] = acc[r][nt][i];
+        }
+      }
+    }
+}
+
 // generic fallback (any channel counts): one thread per (row, out channel); fp32 FMA-free sums
 __global__ __launch_bounds__(256) void spconv_scalar_kernel(const float *__restrict__ in, int Kdim,
                                                             const float *__restrict__ W, int Cout_w,
@@ -748,6 +928,18 @@ void launch_gemm(int R, int blocks_rows, hipStream_t stream, const float *in, in
     hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
 }
 
+template <int NT>
+void launch_gemm_bf16(int R, hipStream_t stream, const float *in, int Kdim, const bf16x8 *Wp, const int *pairs,
+                      int ld, int KV, int n_rows, int Ndim, const int *perm, const unsigned *row_mask, float *out) {
+  auto grid = [&](int r) { return dim3(ceil_div(n_rows, 4 * r * 16)); };
+  if (R == 1)
+    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 1>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+  else if (R == 2)
+    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 2>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+  else
+    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+}
+
 }  // namespace
 }  // namespace bfhip
 
@@ -962,6 +1154,40 @@ BFHIP_EXPORT int bfhip_spconv_gemm(const float *in, const float *W, const int32_
   }
   prof_end(&ps);
   return check_launch("spconv_gemm");
+}
+
+// Same contract as bfhip_spconv_gemm with bf16 MFMA inputs (features/weights rounded to bf16 on load,
+// fp32 accumulate and output): the bf16 configs (the reference runs spconv in half precision under AMP).
+// Requires Kdim % 8 == 0; other shapes are rejected (use the fp32 entry point).
+BFHIP_EXPORT int bfhip_spconv_gemm_bf16(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
+                                        int n_rows, int Cin, int Cout, int transpose, int flip,
+                                        const int32_t *perm, const uint32_t *row_mask, float *out,
+                                        void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BFHIP_REQUIRE(KV > 0 && KV <= 32 && Cin > 0 && Cout > 0 && n_rows >= 0 && ld >= n_rows, "spconv_gemm_bf16: bad sizes");
+  if (n_rows == 0) return BFHIP_OK;
+  BFHIP_REQUIRE(in && W && pairs && out, "spconv_gemm_bf16: null pointer");
+  int Kdim = transpose ? Cout : Cin, Ndim = transpose ? Cin : Cout;
+  int NT = (Ndim + 15) / 16, CC32 = (Kdim + 31) / 32;
+  BFHIP_REQUIRE(Kdim % 8 == 0 && ((uintptr_t)in % 16 == 0) && (NT == 1 || NT == 2 || NT == 4 || NT == 8),
+                "spconv_gemm_bf16: needs K %% 8 == 0, N in {16,32,64,128} (padded), 16-byte aligned features");
+  if (workspace_bytes < bfhip_spconv_workspace_bytes(KV, Cin, Cout) || !workspace) { set_error("spconv_gemm_bf16: workspace too small"); return BFHIP_E_WORKSPACE; }
+  __bf16 *Wp = (__bf16 *)workspace;
+  ProfScope ps;
+  prof_begin(transpose ? BFHIP_OP_SPCONV_BWD : BFHIP_OP_SPCONV_FWD, stream, &ps);
+  long long total = (long long)KV * CC32 * NT * 512;
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, W, Cout, KV, Cin, transpose,
+                     flip, CC32, NT, Wp);
+  int R = n_rows >= 262144 ? 4 : (n_rows >= 65536 ? 2 : 1);
+  const bf16x8 *wp = (const bf16x8 *)Wp;
+  switch (NT) {
+    case 1: launch_gemm_bf16<1>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+    case 2: launch_gemm_bf16<2>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+    case 4: launch_gemm_bf16<4>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+    default: launch_gemm_bf16<8>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+  }
+  prof_end(&ps);
+  return check_launch("spconv_gemm_bf16");
 }
 
 // wgrad: dW (Cout,KV,Cin) = sum_n dout[n] (x) in[pairs[k][n]]

@@ -123,14 +123,21 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
                       conv_out_shape(spatial_shape, ksize, stride, padding, dilation), ksize, stride, padding, dilation)
 
 
-def _gemm(inp, weight, pairs, n_rows, transpose, flip, perm=None, row_mask=None):
+def _bf16_ok(weight, transpose):
+    cout, cin = weight.shape[0], weight.shape[-1]
+    kdim, ndim = (cout, cin) if transpose else (cin, cout)
+    return kdim % 8 == 0 and ndim in (16, 32, 64, 128) or (kdim % 8 == 0 and ndim <= 128 and (ndim + 15) // 16 in (1, 2, 4, 8))
+
+
+def _gemm(inp, weight, pairs, n_rows, transpose, flip, perm=None, row_mask=None, bf16=False):
     cout, cin = weight.shape[0], weight.shape[-1]
     kv = pairs.shape[0]
     out = torch.empty((n_rows, cin if transpose else cout), dtype=torch.float32, device=inp.device)
     lib = _lib.load()
     ws = _workspace(inp.device, lib.bfhip_spconv_workspace_bytes(kv, cin, cout), "gemm")
+    fn = lib.bfhip_spconv_gemm_bf16 if (bf16 and _bf16_ok(weight, transpose)) else lib.bfhip_spconv_gemm
     with torch.cuda.device(inp.device):
-        rc = lib.bfhip_spconv_gemm(_lib.ptr(inp), _lib.ptr(weight), _lib.ptr(pairs), pairs.shape[1], kv, n_rows, cin,
+        rc = fn(_lib.ptr(inp), _lib.ptr(weight), _lib.ptr(pairs), pairs.shape[1], kv, n_rows, cin,
                                    cout, 1 if transpose else 0, 1 if flip else 0, _lib.ptr(perm), _lib.ptr(row_mask),
                                    _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_of(inp))
     _lib.check(rc, "spconv_gemm")
@@ -142,9 +149,13 @@ class _SparseConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, features, weight, data, n_in):
+        # under bf16 autocast the MFMA inputs are rounded to bf16 (fp32 accumulate, fp32 features in HBM), as the
+        # reference's spconv runs in half precision under AMP; index paths and wgrad stay fp32
+        ctx.bf16 = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
         features = features.contiguous().float()
         w = weight.contiguous().float()
-        out = _gemm(features, w, data.pair_fwd, data.pair_fwd.shape[1], False, False, data.perm_fwd, data.mask_fwd)
+        out = _gemm(features, w, data.pair_fwd, data.pair_fwd.shape[1], False, False, data.perm_fwd, data.mask_fwd,
+                    bf16=ctx.bf16)
         ctx.save_for_backward(features, w)
         ctx.data = data
         ctx.n_in = n_in
@@ -160,9 +171,9 @@ class _SparseConvFunction(torch.autograd.Function):
             if data.is_subm:
                 # SubM: pair_fwd doubles as the backward table with flipped offsets; rows with equal masks stay
                 # adjacent under perm_fwd (the flip permutes mask bits), the per-wave masks are recomputed
-                d_feat = _gemm(grad_out, w, data.pair_fwd, ctx.n_in, True, True, data.perm_fwd, data.mask_fwd)
+                d_feat = _gemm(grad_out, w, data.pair_fwd, ctx.n_in, True, True, data.perm_fwd, data.mask_fwd, bf16=ctx.bf16)
             else:
-                d_feat = _gemm(grad_out, w, data.pair_bwd, ctx.n_in, True, False, data.perm_bwd, data.mask_bwd)
+                d_feat = _gemm(grad_out, w, data.pair_bwd, ctx.n_in, True, False, data.perm_bwd, data.mask_bwd, bf16=ctx.bf16)
         if ctx.needs_input_grad[1]:
             cout, cin = w.shape[0], w.shape[-1]
             kv = data.pair_fwd.shape[0]

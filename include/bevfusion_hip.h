@@ -230,6 +230,13 @@ int bfhip_spconv_gemm(const float *in, const float *W, const int32_t *pairs, int
                       int n_rows, int Cin, int Cout, int transpose, int flip, const int32_t *perm,
                       const uint32_t *row_mask, float *out, void *workspace, size_t workspace_bytes,
                       void *stream);
+/* bf16-input variant of bfhip_spconv_gemm (same arguments and workspace size): features and weights are rounded
+ * to bf16 on load, products accumulate in fp32, output fp32.  For the bf16 configs (the reference runs spconv in
+ * half precision under AMP).  Requires K % 8 == 0. */
+int bfhip_spconv_gemm_bf16(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
+                           int n_rows, int Cin, int Cout, int transpose, int flip, const int32_t *perm,
+                           const uint32_t *row_mask, float *out, void *workspace, size_t workspace_bytes,
+                           void *stream);
 size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout, int n_rows);
 int bfhip_spconv_wgrad(const float *in, const float *dout, const int32_t *pairs, int ld, int KV,
                        int n_rows, int Cin, int Cout, const int32_t *perm, float *dW, void *workspace,

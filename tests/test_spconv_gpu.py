@@ -186,3 +186,26 @@ def test_encoder_layer_vs_oracle_end_to_end(dev):
     f2 = oracle.spconv_fwd(f1, c2.weight.detach().cpu().numpy(), pf)
     assert np.array_equal(y.indices.cpu().numpy(), oi)
     assert rel_err(y.features.detach().cpu().numpy(), f2) < TOL
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 64), (128, 128)])
+def test_conv_bf16_autocast_vs_oracle(dev, cin, cout):
+    """Under bf16 autocast the gather-GEMM rounds its MFMA inputs to bf16 (fp32 accumulate): within the 1e-2 rel
+    bf16 tolerance of the north star against the fp64-accumulated oracle; wgrad stays fp32."""
+    B, shape, n = 2, (40, 36, 9), 6000
+    idx, feats = random_sparse(B, shape, n, cin, seed=cin * 3 + cout)
+    conv = SubMConv3d(cin, cout, 3, padding=1, bias=False).to(dev)
+    w = conv.weight.detach().cpu().numpy()
+    x = SparseConvTensor(torch.from_numpy(feats).to(dev).requires_grad_(True), torch.from_numpy(idx).to(dev), shape, B)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = conv(x)
+    assert out.features.dtype == torch.float32
+    pair = oracle.rulebook_subm(idx, shape, 3)
+    want = oracle.spconv_fwd(feats, w, pair)
+    err = rel_err(out.features.detach().cpu().numpy(), want)
+    assert 1e-6 < err < 1e-2, err     # really the bf16 path (not bit-identical to fp32), inside the bf16 budget
+    g = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    out.features.backward(g)
+    d_in, d_w = oracle.spconv_bwd(feats, w, g.cpu().numpy(), pair)
+    assert rel_err(x.features.grad.cpu().numpy(), d_in) < 1e-2
+    assert rel_err(conv.weight.grad.cpu().numpy(), d_w) < TOL     # wgrad is fp32
