@@ -130,6 +130,8 @@ BFHIP_EXPORT int bfhip_rasterise_depth(const float *points, int n, int f, const 
   if (workspace_bytes < bfhip_rasterise_depth_workspace_bytes(ncam, iH, iW) || !workspace) { set_error("rasterise_depth: workspace too small"); return BFHIP_E_WORKSPACE; }
   unsigned long long *winner = (unsigned long long *)workspace;
   long long npix = (long long)ncam * iH * iW;
+  ProfScope ps;
+  prof_begin(BFHIP_OP_RASTER, stream, &ps);
   if (hipMemsetAsync(winner, 0, (size_t)npix * sizeof(unsigned long long), stream) != hipSuccess) return check_launch("rasterise_depth memset");
   if (n > 0) {
     BFHIP_REQUIRE(points, "rasterise_depth: points is null");
@@ -144,6 +146,7 @@ BFHIP_EXPORT int bfhip_rasterise_depth(const float *points, int n, int f, const 
   }
   hipLaunchKernelGGL(raster_resolve_kernel, dim3(ceil_div(npix, 256)), dim3(256), 0, stream, winner, npix, iH, iW, fH, fW, D,
                      lo, cmax, half, step, depth, counts);
+  prof_end(&ps);
   return check_launch("rasterise_depth");
 }
 

@@ -1225,7 +1225,7 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const float *in, const float *dout, const in
   float *partial = (float *)workspace;
   long long waves = (long long)KV * S * GI * GJ;
   ProfScope ps;
-  prof_begin(BFHIP_OP_SPCONV_BWD, stream, &ps);
+  prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
   if (vec)
     hipLaunchKernelGGL(spconv_wgrad64_kernel, dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
                        pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);

@@ -151,7 +151,7 @@ class _SparseConvFunction(torch.autograd.Function):
     def forward(ctx, features, weight, data, n_in):
         # under bf16 autocast the MFMA inputs are rounded to bf16 (fp32 accumulate, fp32 features in HBM), as the
         # reference's spconv runs in half precision under AMP; index paths and wgrad stay fp32
-        ctx.bf16 = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        ctx.bf16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
         features = features.contiguous().float()
         w = weight.contiguous().float()
         out = _gemm(features, w, data.pair_fwd, data.pair_fwd.shape[1], False, False, data.perm_fwd, data.mask_fwd,

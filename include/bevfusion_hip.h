@@ -46,11 +46,13 @@ extern "C" {
 #define BFHIP_OP_LIFT_SPLAT_FWD 4
 #define BFHIP_OP_LIFT_SPLAT_BWD 5
 #define BFHIP_OP_SPCONV_FWD 6
-#define BFHIP_OP_SPCONV_BWD 7
+#define BFHIP_OP_SPCONV_BWD 7 /* dgrad */
 #define BFHIP_OP_RULEBOOK 8
 #define BFHIP_OP_BEV_AUX 9
 #define BFHIP_OP_SCATTER_FWD 10
 #define BFHIP_OP_SCATTER_BWD 11
+#define BFHIP_OP_SPCONV_WGRAD 12
+#define BFHIP_OP_RASTER 13
 #define BFHIP_OP_COUNT 16
 
 int bfhip_abi_version(void);
