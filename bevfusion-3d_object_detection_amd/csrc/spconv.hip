@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__rest
   const int s = (int)(wave % S);
   const int k = (int)(wave / S);
   const int la = lane & 15, lq = lane >> 4;
-  const int rows_per = (((n_rows + S - 1) / S) + 3) & ~3;
+  const int rows_per = (((n_rows + S - 1) / S) + 63) & ~63;
   const int r0 = s * rows_per, r1 = min(n_rows, r0 + rows_per);
   const int ci = gi * 64 + la * 4, co = gj * 64 + la * 4;
   const bool ci_ok = ci < Cin, co_ok = co < Cout;  // Cin, Cout multiples of 4 (checked by the host)
@@ -797,32 +797,47 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__rest
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // On-the-fly compaction: each 64-row chunk keeps only its valid (input row, output row) pairs of offset k
+  // (ballot + prefix popcount into a wave-private LDS list), so every MFMA K-step carries 4 real pairs instead
+  // of ~50 % holes at the dense stages (and ~85 % at stage 1).
+  __shared__ int2 s_list[4][64];
+  int2 *list = s_list[threadIdx.x >> 6];
   constexpr int U = 4;
-  for (int n0 = r0; n0 < r1; n0 += 4 * U) {
-    int p[U], rw[U];
-    bool any = false;
+  for (int chunk = r0; chunk < r1; chunk += 64) {
+    const int row = chunk + lane;
+    const int pr = row < r1 ? pairs[(size_t)k * ld + (perm ? perm[row] : row)] : -1;
+    const unsigned long long vmask = __ballot(pr >= 0);
+    const int cnt = __popcll(vmask);
+    if (cnt == 0) continue;
+    if (pr >= 0) list[__popcll(vmask & ((1ull << lane) - 1ull))] = make_int2(pr, perm ? perm[row] : row);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < cnt; t0 += 4 * U) {
+      int2 e[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int sp = n0 + 4 * u + lq;  // position in mask-sorted order
-      rw[u] = sp < r1 ? (perm ? perm[sp] : sp) : -1;
-      p[u] = rw[u] >= 0 ? pairs[(size_t)k * ld + rw[u]] : -1;
-      any |= p[u] >= 0;
+      for (int u = 0; u < U; ++u) {
+        const int j = t0 + 4 * u + lq;
+        e[u] = j < cnt ? list[j] : make_int2(-1, -1);
+      }
+      f32x4 av[U], bv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = e[u].x >= 0;
+        av[u] = (ok && ci_ok) ? *(const f32x4 *)(in + (size_t)e[u].x * Cin + ci) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bv[u] = (ok && co_ok) ? *(const f32x4 *)(dout + (size_t)e[u].y * Cout + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (t0 + 4 * u < cnt) {  // wave-uniform: skip K-steps past the end of the compacted list
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+              acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
+        }
+      }
     }
-    if (!__any(any)) continue;
-    f32x4 av[U], bv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      bool ok = p[u] >= 0;
-      av[u] = (ok && ci_ok) ? *(const f32x4 *)(in + (size_t)p[u] * Cin + ci) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      bv[u] = (ok && co_ok) ? *(const f32x4 *)(dout + (size_t)rw[u] * Cout + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-          acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
   }
   // D layout: row = (lane>>4)*4 + i -> a (ci = 4a + c), col = lane&15 -> a' (co = 4a' + d)
   float *dst = partial + ((size_t)s * KV + k) * Cin * Cout;
