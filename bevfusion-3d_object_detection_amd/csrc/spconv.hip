@@ -41,6 +41,11 @@ __device__ __forceinline__ unsigned hash32(unsigned k) {
   return k;
 }
 
+__global__ __launch_bounds__(256) void fill_pair_kernel(int2 *__restrict__ t, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) t[i] = make_int2(-1, 0x7f7f7f7f);
+}
+
 __global__ __launch_bounds__(256) void fill_i32_kernel(int *__restrict__ p, long long n, int v) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
@@ -48,50 +53,63 @@ __global__ __launch_bounds__(256) void fill_i32_kernel(int *__restrict__ p, long
 }
 
 // ------------------------------------------------------------------------------- SubM rulebook
+// hash table of (key, row) pairs interleaved in one int2 (one cache line per probe)
 __global__ __launch_bounds__(256) void subm_insert_kernel(const int4 *__restrict__ indices, int N,
-                                                          ConvGeom G, int *__restrict__ keys,
-                                                          int *__restrict__ vals, unsigned mask) {
+                                                          ConvGeom G, int2 *__restrict__ table,
+                                                          unsigned mask) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   int4 c = indices[n];
   int key = ((c.x * G.in0 + c.y) * G.in1 + c.z) * G.in2 + c.w;
   unsigned s = hash32((unsigned)key) & mask;
   for (unsigned probe = 0; probe <= mask; ++probe) {
-    int old = atomicCAS(&keys[s], -1, key);
+    int old = atomicCAS(&table[s].x, -1, key);
     if (old == -1 || old == key) break;
     s = (s + 1) & mask;
   }
-  atomicMin(&vals[s], n);  // duplicate coordinates (malformed input): lowest row wins, deterministically
+  atomicMin(&table[s].y, n);  // duplicate coordinates (malformed input): lowest row wins, deterministically
 }
 
+// blockIdx.y = kernel offset k in the LOWER half (k <= KV/2).  A submanifold rulebook is symmetric:
+// pair[k][n] = j  <=>  pair[KV-1-k][j] = n, so each found neighbour fills two entries and only half of the
+// offsets are probed; the centre offset maps every row to itself.  pair_fwd must be pre-filled with -1.
 __global__ __launch_bounds__(256) void subm_pairs_kernel(const int4 *__restrict__ indices, int N,
-                                                         ConvGeom G, const int *__restrict__ keys,
-                                                         const int *__restrict__ vals, unsigned mask,
-                                                         int *__restrict__ pair_fwd,
-                                                         int *__restrict__ n_pairs) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int k = (int)(t / N);
-  int n = (int)(t - (long long)k * N);
+                                                         ConvGeom G, const int2 *__restrict__ table,
+                                                         unsigned mask, int *__restrict__ pair_fwd,
+                                                         int *__restrict__ n_pairs, int symmetric) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
   int found = -1;
-  if (k < G.KV) {
+  if (n < N) {
     int4 c = indices[n];
     int l = k % G.k2, j = (k / G.k2) % G.k1, i = k / (G.k2 * G.k1);
-    int x = c.y + (i - G.k0 / 2) * G.d0, y = c.z + (j - G.k1 / 2) * G.d1, z = c.w + (l - G.k2 / 2) * G.d2;
-    if (x >= 0 && x < G.in0 && y >= 0 && y < G.in1 && z >= 0 && z < G.in2) {
-      int key = ((c.x * G.in0 + x) * G.in1 + y) * G.in2 + z;
-      unsigned s = hash32((unsigned)key) & mask;
-      for (unsigned probe = 0; probe <= mask; ++probe) {
-        int kk = keys[s];
-        if (kk == key) { found = vals[s]; break; }
-        if (kk == -1) break;
-        s = (s + 1) & mask;
+    int dx_ = (i - G.k0 / 2) * G.d0, dy_ = (j - G.k1 / 2) * G.d1, dz_ = (l - G.k2 / 2) * G.d2;
+    if (dx_ == 0 && dy_ == 0 && dz_ == 0) {
+      found = n;
+    } else {
+      int x = c.y + dx_, y = c.z + dy_, z = c.w + dz_;
+      if (x >= 0 && x < G.in0 && y >= 0 && y < G.in1 && z >= 0 && z < G.in2) {
+        int key = ((c.x * G.in0 + x) * G.in1 + y) * G.in2 + z;
+        unsigned s = hash32((unsigned)key) & mask;
+        for (unsigned probe = 0; probe <= mask; ++probe) {
+          int2 e = table[s];
+          if (e.x == key) { found = e.y; break; }
+          if (e.x == -1) break;
+          s = (s + 1) & mask;
+        }
       }
     }
-    pair_fwd[t] = found;
+    if (found >= 0) {
+      pair_fwd[(size_t)k * N + n] = found;
+      if (symmetric && k != G.KV - 1 - k) pair_fwd[(size_t)(G.KV - 1 - k) * N + found] = n;
+    }
   }
   // pair statistics: spread over 64 counters (one hot word saturates at ~88 atomics/us); summed by the host wrapper
   unsigned long long bal = __ballot(found >= 0);
-  if (n_pairs && (threadIdx.x & 63) == 0 && bal) atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], __popcll(bal));
+  if (n_pairs && (threadIdx.x & 63) == 0 && bal) {
+    int add = __popcll(bal) * ((symmetric && k != G.KV - 1 - k) ? 2 : 1);
+    atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6) + k) & 63], add);
+  }
 }
 
 // ---------------------------------------------------------------------------- strided rulebook
@@ -108,10 +126,9 @@ __device__ __forceinline__ bool out_coord(const ConvGeom &G, int4 c, int k, int 
 
 __global__ __launch_bounds__(256) void sparse_mark_kernel(const int4 *__restrict__ indices, int N,
                                                           ConvGeom G, unsigned *__restrict__ bitmap) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int k = (int)(t / N);
-  int n = (int)(t - (long long)k * N);
-  if (k >= G.KV) return;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (n >= N) return;
   int ox, oy, oz;
   int4 c = indices[n];
   if (!out_coord(G, c, k, ox, oy, oz)) return;
@@ -211,11 +228,11 @@ __global__ __launch_bounds__(256) void sparse_pairs_kernel(const int4 *__restric
                                                            int ld_out, int *__restrict__ pair_fwd,
                                                            int *__restrict__ pair_bwd,
                                                            int *__restrict__ n_pairs) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int k = (int)(t / N);
-  int n = (int)(t - (long long)k * N);
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  const long long t = (long long)k * N + n;
   bool ok = false;
-  if (k < G.KV) {
+  if (n < N) {
     int ox, oy, oz;
     int4 c = indices[n];
     ok = out_coord(G, c, k, ox, oy, oz);
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(256) void sparse_pairs_kernel(const int4 *__restric
     pair_bwd[t] = o;
   }
   unsigned long long bal = __ballot(ok);
-  if (n_pairs && (threadIdx.x & 63) == 0 && bal) atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 63], __popcll(bal));
+  if (n_pairs && (threadIdx.x & 63) == 0 && bal) atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6) + k) & 63], __popcll(bal));
 }
 
 // -------------------------------------------------------------------------------- row masks
@@ -970,7 +987,7 @@ BFHIP_EXPORT int bfhip_conv_out_shape(const int *in_shape, const int *ksize, con
 }
 
 BFHIP_EXPORT size_t bfhip_rulebook_subm_workspace_bytes(int N) {
-  return 2 * align_up((size_t)table_cap(N > 0 ? N : 1) * sizeof(int), 256) + 256;
+  return align_up((size_t)table_cap(N > 0 ? N : 1) * sizeof(int2), 256) + 256;
 }
 
 BFHIP_EXPORT int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const int *in_shape,
@@ -992,17 +1009,22 @@ BFHIP_EXPORT int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const
   }
   Workspace ws(workspace, workspace_bytes);
   unsigned cap = table_cap(N);
-  int *keys = ws.take<int>(cap), *vals = ws.take<int>(cap);
+  int2 *table = ws.take<int2>(cap);
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
-  hipMemsetAsync(keys, 0xff, cap * sizeof(int), stream);
-  hipMemsetAsync(vals, 0x7f, cap * sizeof(int), stream);
+  {
+    long long words = (long long)cap * 2;
+    hipLaunchKernelGGL(fill_pair_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, stream, table, (int)cap);
+    (void)words;
+  }
+  hipMemsetAsync(pair_fwd, 0xff, (size_t)G.KV * N * sizeof(int), stream);
   hipLaunchKernelGGL(subm_insert_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, stream, (const int4 *)indices, N, G,
-                     keys, vals, cap - 1);
-  long long total = (long long)G.KV * N;
-  long long padded = ceil_div(total, 64) * 64LL;
-  hipLaunchKernelGGL(subm_pairs_kernel, dim3(ceil_div(padded, 256)), dim3(256), 0, stream, (const int4 *)indices, N,
-                     G, keys, vals, cap - 1, pair_fwd, n_pairs_dev);
+                     table, cap - 1);
+  // odd kernel sizes with unit dilation symmetry: probe offsets 0..KV/2 only
+  const int symmetric = (G.k0 % 2 == 1) && (G.k1 % 2 == 1) && (G.k2 % 2 == 1);
+  const int nk = symmetric ? G.KV / 2 + 1 : G.KV;
+  hipLaunchKernelGGL(subm_pairs_kernel, dim3(ceil_div(N, 256), nk), dim3(256), 0, stream, (const int4 *)indices, N,
+                     G, table, cap - 1, pair_fwd, n_pairs_dev, symmetric);
   prof_end(&ps);
   return check_launch("rulebook_subm");
 }
@@ -1046,8 +1068,7 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_count(const int32_t *indices, int N, int 
   hipMemsetAsync(bitmap, 0, nwords * sizeof(unsigned), stream);
   hipMemsetAsync(counts_dev, 0, 65 * sizeof(int), stream);
   if (N > 0) {
-    long long total = (long long)G.KV * N;
-    hipLaunchKernelGGL(sparse_mark_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, (const int4 *)indices, N, G, bitmap);
+    hipLaunchKernelGGL(sparse_mark_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, G, bitmap);
   }
   hipLaunchKernelGGL(words_count_kernel, dim3(nb), dim3(kScan), 0, stream, bitmap, nwords, blk);
   hipLaunchKernelGGL(blocks_scan_kernel, dim3(1), dim3(kScan), 0, stream, blk, nb, counts_dev);
@@ -1080,9 +1101,7 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B
   hipMemsetAsync(pair_fwd, 0xff, (size_t)G.KV * n_out * sizeof(int), stream);
   hipLaunchKernelGGL(sparse_out_indices_kernel, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream, bitmap, word_prefix,
                      nwords, G, n_out, (int4 *)out_indices);
-  long long total = (long long)G.KV * N;
-  long long padded = ceil_div(total, 64) * 64LL;
-  hipLaunchKernelGGL(sparse_pairs_kernel, dim3(ceil_div(padded, 256)), dim3(256), 0, stream, (const int4 *)indices, N, G,
+  hipLaunchKernelGGL(sparse_pairs_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, G,
                      bitmap, word_prefix, n_out, pair_fwd, pair_bwd, counts_dev + 1);
   prof_end(&ps);
   return check_launch("rulebook_sparse_fill");
