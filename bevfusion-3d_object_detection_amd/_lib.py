@@ -59,6 +59,10 @@ SIGNATURES = {
     "bfhip_rasterise_depth": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 4 + [_c_int] * 3 + [_c_vp, _c_vp] + [_c_int] * 3 +
                               [_c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_depth_histogram": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_vp, _c_vp]),
+    "bfhip_bn1d_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "bfhip_bn1d_fwd": (_c_int, [_c_vp] * 4 + [_c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] + [_c_vp] * 4 +
+                       [_c_vp, _c_sz, _c_vp]),
+    "bfhip_bn1d_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 3 + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
 }
 
 _lib = None

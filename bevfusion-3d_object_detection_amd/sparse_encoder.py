@@ -9,8 +9,8 @@ import torch
 from torch import nn
 
 from .registry import MODELS
-from .spconv import (SparseConv3d, SparseConvTensor, SparseModule, SparseSequential, SubMConv3d,  # noqa: F401
-                     replace_feature)
+from .spconv import (BatchNorm1dAct, SparseConv3d, SparseConvTensor, SparseModule, SparseSequential,  # noqa: F401
+                     SubMConv3d, replace_feature)
 
 _CONV_TYPES = {"SubMConv3d": SubMConv3d, "SparseConv3d": SparseConv3d}
 
@@ -20,7 +20,7 @@ def build_norm_1d(norm_cfg, channels):
     typ = cfg.pop("type")
     assert typ in ("BN1d", "BN"), typ
     cfg.pop("requires_grad", None)
-    return nn.BatchNorm1d(channels, **cfg)
+    return BatchNorm1dAct(channels, **cfg)  # nn.BatchNorm1d with fused (+residual)(+ReLU) HIP kernels in training
 
 
 def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0,
@@ -62,12 +62,12 @@ class SparseBasicBlock(SparseModule):
         identity = x.features
         assert x.features.dim() == 2
         out = self.conv1(x)
-        out = replace_feature(out, self.relu(self.norm1(out.features)))
+        out = replace_feature(out, self.norm1(out.features, relu=True))
         out = self.conv2(out)
-        out = replace_feature(out, self.norm2(out.features))
         if self.downsample is not None:
             identity = self.downsample(x).features
-        return replace_feature(out, self.relu(out.features + identity))
+        # norm2 + identity + ReLU in one pass
+        return replace_feature(out, self.norm2(out.features, residual=identity, relu=True))
 
 
 @MODELS.register_module()

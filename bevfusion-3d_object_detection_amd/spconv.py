@@ -266,6 +266,66 @@ class SparseConvTensor:
         return _ToBevFunction.apply(self.features, self.indices, self.batch_size, X, Y, Z)
 
 
+class _BN1dFunction(torch.autograd.Function):
+    """y = act(BN_train(x) [+ residual]) on f32[N, C] (csrc/bn1d.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu):
+        x = x.contiguous()
+        N, C = x.shape
+        res = residual.contiguous() if residual is not None else None
+        y = torch.empty_like(x)
+        stats = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        ws = _workspace(x.device, lib.bfhip_bn1d_workspace_bytes(N, C), "bn1d")
+        with torch.cuda.device(x.device):
+            rc = lib.bfhip_bn1d_fwd(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), N, C, float(eps),
+                                    float(momentum), 1 if relu else 0, _lib.ptr(running_mean), _lib.ptr(running_var),
+                                    _lib.ptr(stats), _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
+        _lib.check(rc, "bn1d_fwd")
+        ctx.save_for_backward(x, y, stats, weight)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, stats, weight = ctx.saved_tensors
+        N, C = x.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgb = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        ws = _workspace(x.device, lib.bfhip_bn1d_workspace_bytes(N, C), "bn1d")
+        with torch.cuda.device(x.device):
+            rc = lib.bfhip_bn1d_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(weight), N, C,
+                                    1 if ctx.relu else 0, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgb), _lib.ptr(ws),
+                                    ws.numel(), _lib.stream_of(x))
+        _lib.check(rc, "bn1d_bwd")
+        return dx, dres, dgb[:C], dgb[C:], None, None, None, None, None
+
+
+class BatchNorm1dAct(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters / buffers / state_dict keys) whose forward can also add a residual and apply
+    ReLU; in training mode on fp32 CUDA features of a supported width it runs the fused HIP kernels."""
+
+    def forward(self, x, residual=None, relu=False):
+        C = x.shape[1] if x.dim() == 2 else 0
+        fused = (self.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 1
+                 and self.affine and self.track_running_stats and self.momentum is not None
+                 and C % 4 == 0 and C <= 256 and 256 % C == 0)
+        if fused:
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return _BN1dFunction.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                       self.momentum, relu)
+        out = super().forward(x)
+        if residual is not None:
+            out = out + residual
+        return torch.relu(out) if relu else out
+
+
 class SparseModule(nn.Module):
     """Marker base class: modules that take and return a SparseConvTensor."""
 
@@ -298,14 +358,22 @@ class SparseSequential(SparseModule):
         self.add_module(name if name is not None else str(len(self._modules)), module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
+                    if isinstance(module, BatchNorm1dAct) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                        input = input.replace_feature(module(input.features, relu=True))  # BN + ReLU in one pass
+                        i += 1
+                    else:
+                        input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
+            i += 1
         return input
 
 

@@ -266,6 +266,23 @@ int bfhip_rasterise_depth(const float *points, int n, int f, const float *inv_ro
 int bfhip_depth_histogram(const float *depth, int BN, int iH, int iW, int fH, int fW, int D,
                           const float *dbound_host, float *counts, float *distr, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm1d (+ residual) (+ ReLU) on sparse feature matrices f32[N, C], training mode  (SURVEY 8 f-4;
+ *   replaces the BN1d / add / ReLU torch kernels after every sparse conv,
+ *   mmdet3d/models/layers/sparse_block.py:135-154,157-224; norm_cfg BN1d eps 1e-3 momentum 0.01)
+ *   fwd: stats f32[2C] <- (batch mean, 1/sqrt(biased var + eps)); running stats updated like torch
+ *        (running_var with the unbiased variance); y = act(gamma * (x - mean) * invstd + beta [+ residual])
+ *   bwd: dgb f32[2C] <- (dgamma, dbeta); dx; dres (optional) = gradient of the residual input
+ *   C must divide 256 and be a multiple of 4; tensors 16-byte aligned.
+ * --------------------------------------------------------------------------------------- */
+size_t bfhip_bn1d_workspace_bytes(int N, int C);
+int bfhip_bn1d_fwd(const float *x, const float *residual, const float *gamma, const float *beta, int N, int C,
+                   float eps, float momentum, int relu, float *running_mean, float *running_var, float *stats,
+                   float *y, void *workspace, size_t workspace_bytes, void *stream);
+int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x, const float *stats, const float *gamma, int N,
+                   int C, int relu, float *dx, float *dres, float *dgb, void *workspace, size_t workspace_bytes,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,3 +209,42 @@ def test_conv_bf16_autocast_vs_oracle(dev, cin, cout):
     d_in, d_w = oracle.spconv_bwd(feats, w, g.cpu().numpy(), pair)
     assert rel_err(x.features.grad.cpu().numpy(), d_in) < 1e-2
     assert rel_err(conv.weight.grad.cpu().numpy(), d_w) < TOL     # wgrad is fp32
+
+
+@pytest.mark.parametrize("C,res,relu", [(16, False, True), (32, True, True), (64, False, False), (128, True, True)])
+def test_fused_bn1d_matches_torch(dev, C, res, relu):
+    """BatchNorm1dAct (csrc/bn1d.hip) vs torch BatchNorm1d [+ add] [+ relu]: outputs, running stats and all gradients."""
+    from bevfusion_amd.spconv import BatchNorm1dAct
+    N = 30011
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(N, C, generator=g) * 2 + 0.5).to(dev)
+    r = torch.randn(N, C, generator=g).to(dev) if res else None
+    bn = BatchNorm1dAct(C, eps=1e-3, momentum=0.01).to(dev).train()
+    ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        ref.weight.copy_(bn.weight); ref.bias.copy_(bn.bias)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    r1 = r.clone().requires_grad_(True) if res else None
+    r2 = r.clone().requires_grad_(True) if res else None
+    y = bn(x1, residual=r1, relu=relu)
+    yr = ref(x2)
+    if res:
+        yr = yr + r2
+    if relu:
+        yr = torch.relu(yr)
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    go = torch.randn(N, C, generator=g).to(dev)
+    y.backward(go)
+    yr.backward(go)
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
+    if res:
+        assert torch.allclose(r1.grad, r2.grad, rtol=1e-5, atol=1e-6)
+    # eval mode and unsupported widths fall back to torch's own kernels with identical semantics
+    bn.eval(); ref.eval()
+    assert torch.allclose(bn(x, relu=relu), torch.relu(ref(x)) if relu else ref(x), rtol=1e-5, atol=1e-5)
