@@ -266,6 +266,9 @@ class SparseConvTensor:
         return _ToBevFunction.apply(self.features, self.indices, self.batch_size, X, Y, Z)
 
 
+FUSED_BN1D = os.environ.get("BFHIP_FUSED_BN1D", "1") == "1"  # A/B switch; the torch path has identical semantics
+
+
 class _BN1dFunction(torch.autograd.Function):
     """y = act(BN_train(x) [+ residual]) on f32[N, C] (csrc/bn1d.hip)."""
 
@@ -312,7 +315,7 @@ class BatchNorm1dAct(nn.BatchNorm1d):
 
     def forward(self, x, residual=None, relu=False):
         C = x.shape[1] if x.dim() == 2 else 0
-        fused = (self.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 1
+        fused = (FUSED_BN1D and self.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 1
                  and self.affine and self.track_running_stats and self.momentum is not None
                  and C % 4 == 0 and C <= 256 and 256 % C == 0)
         if fused:
