@@ -14,7 +14,7 @@
 namespace bfhip {
 namespace {
 
-constexpr int kSlab = 512;  // rows per block
+constexpr int kSlab = 64;  // rows per block (many small slabs: the reductions are latency-bound, not byte-bound)
 
 // partial[blk][0][c] = sum_x, partial[blk][1][c] = sum_x2 over the slab.  256 threads: (256 / C) row lanes x C channels
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ x, int N, int C,
@@ -40,19 +40,40 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__
   }
 }
 
+// one block per channel: 256 threads sum the slab partials in a fixed order (thread t takes slabs t, t+256, ...;
+// then a fixed LDS tree), fp64.  returns (sum0, sum1) in every thread.
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nblk, int C, int c,
+                                                double &s, double &s2) {
+  __shared__ double sm[2][256];
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 256) {
+    a += (double)partial[((size_t)k * 2 + 0) * C + c];
+    b += (double)partial[((size_t)k * 2 + 1) * C + c];
+  }
+  sm[0][threadIdx.x] = a;
+  sm[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + o];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  s = sm[0][0];
+  s2 = sm[1][0];
+}
+
 // stats[0][c] = mean, stats[1][c] = invstd; running stats updated like torch (unbiased var in running_var)
-__global__ __launch_bounds__(128) void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N,
                                                           int C, float eps, float momentum,
                                                           float *__restrict__ stats,
                                                           float *__restrict__ running_mean,
                                                           float *__restrict__ running_var) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[((size_t)b * 2 + 0) * C + c];
-    s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x;
+  double s, s2;
+  reduce_partials(partial, nblk, C, c, s, s2);
+  if (threadIdx.x != 0) return;
   double mean = s / N;
   double var = s2 / N - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -118,17 +139,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
 }
 
 // dgb[0][c] = dgamma, dgb[1][c] = dbeta
-__global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C,
                                                               float *__restrict__ dgb) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[((size_t)b * 2 + 0) * C + c];
-    s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+  const int c = blockIdx.x;
+  double s, s2;
+  reduce_partials(partial, nblk, C, c, s, s2);
+  if (threadIdx.x == 0) {
+    dgb[c] = (float)s2;
+    dgb[C + c] = (float)s;
   }
-  dgb[c] = (float)s2;
-  dgb[C + c] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y,
@@ -184,7 +203,7 @@ BFHIP_EXPORT int bfhip_bn1d_fwd(const float *x, const float *residual, const flo
   float *partial = (float *)workspace;
   int nblk = ceil_div(N, kSlab);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, stream, x, N, C, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, partial, nblk, N, C, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, nblk, N, C, eps, momentum,
                      stats, running_mean, running_var);
   long long total4 = (long long)N * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, stream, (const float4 *)x,
@@ -203,7 +222,7 @@ BFHIP_EXPORT int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x,
   float *partial = (float *)workspace;
   int nblk = ceil_div(N, kSlab);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, dy, y, x, stats, N, C, relu, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, partial, nblk, C, dgb);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, nblk, C, dgb);
   long long total4 = (long long)N * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, stream, (const float4 *)dy,
                      (const float4 *)y, (const float4 *)x, stats, gamma, dgb, total4, C, N, relu, (float4 *)dx,
