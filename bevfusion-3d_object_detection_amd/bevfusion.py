@@ -126,6 +126,12 @@ class BEVFusion(nn.Module):
         points = batch_inputs_dict.get("points", None)
         features = []
         depth_loss = 0.0
+        # LiDAR branch first: its host reads (voxel counts, one N_out per strided sparse conv) then happen while the
+        # stream is nearly empty, and the long camera branch is queued behind them with no further sync
+        # (the reference runs camera first, BF/bevfusion.py:305-361; the fused feature order [img, pts] is unchanged)
+        pts_feature = None
+        if self.pts_middle_encoder is not None and points is not None:
+            pts_feature = self.extract_pts_feat(batch_inputs_dict)
         if imgs is not None and self.view_transform is not None:
             mats = {}
             for key, meta_key in (("lidar2img", "lidar2img"), ("cam2img", "cam2img"), ("cam2lidar", "cam2lidar"),
@@ -141,8 +147,8 @@ class BEVFusion(nn.Module):
                                                             mats["lidar_aug_matrix"], batch_input_metas,
                                                             geom_feats=batch_inputs_dict.get("geom_feats"))
             features.append(img_feature)
-        if self.pts_middle_encoder is not None and points is not None:
-            features.append(self.extract_pts_feat(batch_inputs_dict))
+        if pts_feature is not None:
+            features.append(pts_feature)
         if self.fusion_layer is not None:
             x = self.fusion_layer(features)
         else:

@@ -4,7 +4,7 @@
 // SparseBasicBlock adds the identity before its last ReLU (mmdet3d/models/layers/sparse_block.py:135-154,
 // make_sparse_convmodule :157-224); torch runs that as 4-6 generic kernels per layer that are latency-bound at
 // these sizes (N = 26 k - 136 k rows, C = 16 - 128: ~48 us for a 17 MB column reduction).  Here:
-//   forward : column sum / sum of squares per 512-row slab (fp32 partials, fp64 combine) -> mean, biased var,
+//   forward : column sum / sum of squares per 64-row slab (fp32 partials, fp64 combine) -> mean, biased var,
 //             running-stat update -> y = relu(gamma * (x - mean) * invstd + beta [+ residual])
 //   backward: g = dy * (y > 0);  dbeta = sum g, dgamma = sum g * xhat  (slab partials, fp64 combine)
 //             dx = gamma * invstd * (g - dbeta/N - xhat * dgamma/N);  d_residual = g
