@@ -176,6 +176,7 @@ class _ModelWorkload:
                     sub.to(memory_format=torch.channels_last)
         if self.amp and getattr(self.model, "view_transform", None) is not None:
             self.model.view_transform.conv_dtype = torch.bfloat16  # dense convs bf16, index paths + pooling fp32
+        self.model.lidar_side_stream = os.environ.get("BENCH_SIDE_STREAM", "1") == "1"
         torch.backends.cudnn.benchmark = MIOPEN_FIND               # MIOpen exhaustive find (minutes of warm-up on a fresh box)
         self.n_params = sum(p.numel() for p in self.model.parameters())
         self.step_model = self.model
