@@ -61,3 +61,26 @@ def test_full_model_forward_backward_bf16(dev):
         grads = [p.grad for p in getattr(model, name).parameters() if p.requires_grad]
         assert all(g is not None and torch.isfinite(g).all() for g in grads), name
     assert model.view_transform.depthnet[0].weight.grad.abs().sum() > 0
+
+
+def test_side_stream_matches_single_stream(dev):
+    """LiDAR branch on a second HIP stream: same features and same gradients as the single-stream run."""
+    torch.manual_seed(0)
+    model = MODELS.build(nuscenes_config()).to(dev).train()
+    inp = _inputs(dev, 1)
+    results = []
+    for side in (False, True):
+        model.lidar_side_stream = side
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(1)  # dropout in the decoder layer
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            feats, depth_loss = model.extract_feat(inp)
+            loss = feats[0].float().square().mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        results.append((feats[0].detach().float().clone(), model.pts_middle_encoder.conv_input[0].weight.grad.clone(),
+                        model.view_transform.depthnet[0].weight.grad.clone()))
+    (f0, g0, d0), (f1, g1, d1) = results
+    assert torch.allclose(f0, f1, rtol=2e-2, atol=2e-2)          # dense bf16 layers: BN running stats differ by one update
+    assert torch.allclose(g0, g1, rtol=5e-2, atol=1e-4 * float(g0.abs().max()) + 1e-8)
+    assert torch.allclose(d0, d1, rtol=5e-2, atol=1e-3 * float(d0.abs().max()) + 1e-8)
