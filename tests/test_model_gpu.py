@@ -64,23 +64,29 @@ def test_full_model_forward_backward_bf16(dev):
 
 
 def test_side_stream_matches_single_stream(dev):
-    """LiDAR branch on a second HIP stream: same features and same gradients as the single-stream run."""
+    """LiDAR branch on a second HIP stream (overlapping the camera branch): its features and, through autograd, its
+    gradients are bit-identical to the single-stream run.  (The MIOpen bf16 image backbone is not bit-reproducible
+    run to run -- tools/side_dbg.py -- so the comparison is made on the deterministic LiDAR branch.)"""
     torch.manual_seed(0)
     model = MODELS.build(nuscenes_config()).to(dev).train()
     inp = _inputs(dev, 1)
+    captured = {}
+    hook = model.pts_middle_encoder.register_forward_hook(lambda m, i, o: captured.__setitem__("pts", o))
+    weight = torch.randn(1, 256, 180, 180, device=dev)
     results = []
     for side in (False, True):
         model.lidar_side_stream = side
         model.zero_grad(set_to_none=True)
-        torch.manual_seed(1)  # dropout in the decoder layer
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            feats, depth_loss = model.extract_feat(inp)
-            loss = feats[0].float().square().mean()
-        loss.backward()
+            feats, _ = model.extract_feat(inp)
+        pts = captured["pts"]
+        (pts * weight).sum().backward(retain_graph=False)
         torch.cuda.synchronize()
-        results.append((feats[0].detach().float().clone(), model.pts_middle_encoder.conv_input[0].weight.grad.clone(),
-                        model.view_transform.depthnet[0].weight.grad.clone()))
-    (f0, g0, d0), (f1, g1, d1) = results
-    assert torch.allclose(f0, f1, rtol=2e-2, atol=2e-2)          # dense bf16 layers: BN running stats differ by one update
-    assert torch.allclose(g0, g1, rtol=5e-2, atol=1e-4 * float(g0.abs().max()) + 1e-8)
-    assert torch.allclose(d0, d1, rtol=5e-2, atol=1e-3 * float(d0.abs().max()) + 1e-8)
+        enc = model.pts_middle_encoder
+        results.append((pts.detach().clone(), enc.conv_input[0].weight.grad.clone(), enc.conv_out[0].weight.grad.clone(),
+                        enc.encoder_layers[1][0].norm2.weight.grad.clone()))
+        assert feats[0].shape == (1, 512, 180, 180)
+    hook.remove()
+    assert model._side_stream is not None
+    for a_, b_ in zip(*results):
+        assert torch.equal(a_, b_)
