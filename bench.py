@@ -354,6 +354,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cpu_mode = args.workload == "dist_selftest"
+    # stdout carries exactly ONE line (the JSON): native libraries write banners to fd 1 (RCCL prints its version block
+    # there on communicator creation), so fd 1 points at stderr for the whole run and the JSON goes to the saved fd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not cpu_mode and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if cpu_mode:
@@ -465,7 +470,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not cpu_mode:
             v, sample = wl.cpu_baseline(args.cpu_frames)
             line["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if cpu_mode and os.environ.get("BENCH_FINGERPRINT_DIR"):  # every rank: DDP must leave identical gradients
         with open(os.path.join(os.environ["BENCH_FINGERPRINT_DIR"], "rank%d.txt" % rank), "w") as fh:
             fh.write(repr(wl.grad_fingerprint()))
