@@ -330,7 +330,27 @@ class BatchNorm1dAct(nn.BatchNorm1d):
 
 
 class SparseModule(nn.Module):
-    """Marker base class: modules that take and return a SparseConvTensor."""
+    """Base class of modules that take and return a SparseConvTensor.
+
+    Checkpoint import (write_spconv2.py:33-34,43-74): state dicts written by spconv 2.x carry module version 2 and
+    store conv kernels as (out, k0, k1, k2, in) — this package's layout; anything older (MMCV spconv 1.x,
+    version None/1) stores (k0, k1, k2, in, out) and is rotated last-dim-first on load.
+    """
+
+    _version = 2
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        if local_metadata.get("version", None) != 2:
+            for name, param in self._parameters.items():
+                key = prefix + name
+                if param is None or key not in state_dict:
+                    continue
+                src = state_dict[key]
+                if src.dim() >= 1:  # same rule for every tensor of the module, as the reference applies it
+                    state_dict[key] = src.permute(src.dim() - 1, *range(src.dim() - 1))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
 
 
 def is_spconv_module(m):
