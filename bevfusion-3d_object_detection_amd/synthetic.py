@@ -178,3 +178,35 @@ def gen_dx_bx(xbound=NUSC["xbound"], ybound=NUSC["ybound"], zbound=NUSC["zbound"
     bx = torch.tensor([r[0] + r[2] / 2.0 for r in rows], dtype=torch.float32)
     nx = torch.tensor([int((r[1] - r[0]) / r[2]) for r in rows], dtype=torch.int64)
     return dx, bx, nx
+
+
+# nuScenes detection classes (config class_names order) with typical (dx, dy, dz) metres
+_CLASS_SIZES = np.array([
+    [4.6, 1.95, 1.73],   # car
+    [6.9, 2.5, 2.84],    # truck
+    [6.4, 2.85, 3.2],    # construction_vehicle
+    [11.0, 2.95, 3.5],   # bus
+    [12.3, 2.9, 3.87],   # trailer
+    [0.5, 2.5, 0.98],    # barrier
+    [2.1, 0.77, 1.47],   # motorcycle
+    [1.7, 0.6, 1.28],    # bicycle
+    [0.73, 0.67, 1.77],  # pedestrian
+    [0.41, 0.41, 1.07],  # traffic_cone
+], np.float32)
+_CLASS_FREQ = np.array([0.43, 0.08, 0.013, 0.014, 0.022, 0.13, 0.011, 0.01, 0.20, 0.09])
+
+
+def gt_boxes(seed=3000, n=None, point_cloud_range=NUSC["point_cloud_range"]):
+    """Synthetic ground truth of one frame: boxes f32[G, 9] = (x, y, z_bottom, dx, dy, dz, yaw, vx, vy) in the LiDAR
+    frame (the layout of `LiDARInstance3DBoxes.tensor` with velocities) and labels i64[G].  G ~ U(15, 60) unless given;
+    class frequencies and sizes are nuScenes-like, centres stay inside the detection range."""
+    rs = np.random.RandomState(seed)
+    g = int(rs.randint(15, 61)) if n is None else int(n)
+    labels = rs.choice(10, size=g, p=_CLASS_FREQ / _CLASS_FREQ.sum()).astype(np.int64)
+    lo, hi = np.array(point_cloud_range[:2], np.float32) + 1.0, np.array(point_cloud_range[3:5], np.float32) - 1.0
+    xy = (rs.uniform(0, 1, (g, 2)) * (hi - lo) + lo).astype(np.float32)
+    size = _CLASS_SIZES[labels] * rs.uniform(0.85, 1.2, (g, 3)).astype(np.float32)
+    z = rs.uniform(-2.2, -1.2, (g, 1)).astype(np.float32)
+    yaw = rs.uniform(-np.pi, np.pi, (g, 1)).astype(np.float32)
+    vel = (rs.normal(0, 2.0, (g, 2)) * (rs.uniform(0, 1, (g, 1)) < 0.4)).astype(np.float32)
+    return np.concatenate([xy, z, size, yaw, vel], 1).astype(np.float32), labels

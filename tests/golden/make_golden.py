@@ -232,6 +232,108 @@ def make_lss_goldens():
     print("lss_ref.npz: counts (N', kept, intervals, max len, median len) =", out["full_counts"])
 
 
+# --------------------------------------------------------------------------------------- (C)
+def load_reference_head_utils():
+    """(C) mmdet3d/models/utils/gaussian.py loads as is (numpy + torch only).  projects/BEVFusion/bevfusion/utils.py is
+    loaded BY PATH; its imports that are not installable here get inert placeholders: registry decorators -> identity,
+    `BaseBBoxCoder` / `BaseAssigner` / `AssignResult` / `InstanceData` -> empty base classes.  Only the reference's own
+    pure-torch methods are executed: TransFusionBBoxCoder.encode / .decode, BBoxBEVL1Cost.__call__, IoU3DCost.__call__."""
+    gpath = os.path.join(REF, "mmdet3d/models/utils/gaussian.py")
+    spec = importlib.util.spec_from_file_location("ref_gaussian", gpath)
+    gauss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gauss)
+
+    class _Registry:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    class _Empty:
+        def __init__(self, *a, **k):
+            pass
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mod("mmdet"); mod("mmdet.models")
+    mod("mmdet.models.task_modules", AssignResult=_Empty, BaseAssigner=_Empty, BaseBBoxCoder=_Empty)
+    mod("mmdet3d"); mod("mmdet3d.registry", TASK_UTILS=_Registry(), MODELS=_Registry())
+    mod("mmengine"); mod("mmengine.structures", InstanceData=_Empty)
+    upath = os.path.join(REF, "projects/BEVFusion/bevfusion/utils.py")
+    spec = importlib.util.spec_from_file_location("ref_bevfusion_utils", upath)
+    utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(utils)
+    return gauss, utils
+
+
+def make_head_goldens():
+    gauss, utils = load_reference_head_utils()
+    N = synthetic.NUSC
+    out = {}
+    pc, vs, osf = N["point_cloud_range"], N["voxel_size"], 8
+    coder = utils.TransFusionBBoxCoder(pc_range=pc[:2], out_size_factor=osf, voxel_size=vs[:2],
+                                       post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.0,
+                                       code_size=10)
+    boxes, labels = synthetic.gt_boxes(seed=3000, n=40)
+    out.update(gt_in_sha=sha(boxes), labels_in_sha=sha(labels))
+    # C1: encode (BF/utils.py:33-46)
+    out["encode"] = coder.encode(torch.from_numpy(boxes)).numpy()
+    # C2: decode (BF/utils.py:48-96) on seeded raw head outputs, B=2, P=50
+    g = torch.Generator().manual_seed(77)
+    B, P = 2, 50
+    heat = torch.randn(B, 10, P, generator=g)
+    rot = torch.randn(B, 2, P, generator=g)
+    dim = torch.randn(B, 3, P, generator=g) * 0.5
+    center = torch.rand(B, 2, P, generator=g) * 180
+    height = torch.randn(B, 1, P, generator=g)
+    vel = torch.randn(B, 2, P, generator=g)
+    out.update(dec_heat=heat.numpy(), dec_rot=rot.numpy(), dec_dim=dim.numpy(), dec_center=center.numpy(),
+               dec_height=height.numpy(), dec_vel=vel.numpy())
+    dec = coder.decode(heat.clone(), rot.clone(), dim.clone(), center.clone(), height.clone(), vel.clone())
+    out["dec_boxes"] = torch.stack([d["bboxes"] for d in dec]).numpy()
+    out["dec_scores"] = torch.stack([d["scores"] for d in dec]).numpy()
+    out["dec_labels"] = torch.stack([d["labels"] for d in dec]).numpy()
+    # C3: BBoxBEVL1Cost (BF/utils.py:133-140) and IoU3DCost (:149-151)
+    train_cfg = dict(point_cloud_range=pc)
+    out["l1_cost"] = utils.BBoxBEVL1Cost(0.25)(dec[0]["bboxes"], torch.from_numpy(boxes), train_cfg).numpy()
+    out["iou_cost_of_half"] = utils.IoU3DCost(0.25)(torch.full((2, 3), 0.5)).numpy()
+    # C4: gaussian_radius (gaussian.py:62-92) on fp32 0-dim tensors, as BF/bevfusion_head.py:644-650 calls it
+    hw = np.stack([np.random.RandomState(5).uniform(0.3, 22, 64), np.random.RandomState(6).uniform(0.3, 22, 64)], 1).astype(np.float32)
+    out["radius_hw"] = hw
+    out["radius"] = np.array([float(gauss.gaussian_radius((torch.tensor(h), torch.tensor(w)), min_overlap=0.1)) for h, w in hw],
+                             np.float32)
+    # C5: dense heat-map target: the reference's gaussian_radius + draw_heatmap_gaussian driven by a replay of the loop
+    #     BF/bevfusion_head.py:636-662 (the loop is a method of the head class, which needs mmdet to construct)
+    gt = torch.from_numpy(boxes)
+    grid_size = torch.tensor([1440, 1440, 41])
+    pc_range, voxel_size = torch.tensor(pc), torch.tensor(vs)
+    fms = grid_size[:2] // osf
+    heatmap = gt.new_zeros(10, int(fms[1]), int(fms[0]))
+    radii = []
+    for idx in range(len(gt)):
+        width = gt[idx][3] / voxel_size[0] / osf
+        length = gt[idx][4] / voxel_size[1] / osf
+        if width > 0 and length > 0:
+            radius = gauss.gaussian_radius((length, width), min_overlap=0.1)
+            radius = max(2, int(radius))
+            radii.append(radius)
+            coor_x = (gt[idx][0] - pc_range[0]) / voxel_size[0] / osf
+            coor_y = (gt[idx][1] - pc_range[1]) / voxel_size[1] / osf
+            center_int = torch.tensor([coor_x, coor_y], dtype=torch.float32).to(torch.int32)
+            gauss.draw_heatmap_gaussian(heatmap[labels[idx]], center_int[[1, 0]], radius)
+    out["heatmap"] = heatmap.numpy()
+    out["heatmap_radii"] = np.array(radii, np.int32)
+    np.savez_compressed(os.path.join(HERE, "head_ref.npz"), **out)
+    print("head_ref.npz:", {k: getattr(val, "shape", val) for k, val in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "head":
+        make_head_goldens()
+        sys.exit(0)
     make_voxel_goldens()
     make_lss_goldens()
+    make_head_goldens()
