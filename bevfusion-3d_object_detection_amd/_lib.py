@@ -63,6 +63,15 @@ SIGNATURES = {
     "bfhip_bn1d_fwd": (_c_int, [_c_vp] * 4 + [_c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] + [_c_vp] * 4 +
                        [_c_vp, _c_sz, _c_vp]),
     "bfhip_bn1d_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 3 + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_decode_boxes": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp, _c_vp, _c_vp]),
+    "bfhip_assign_cost": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 +
+                          [_c_vp] * 4),
+    "bfhip_hungarian": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
+    "bfhip_assign_targets": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp] + [_c_int] * 5 + [_c_vp] * 7),
+    "bfhip_draw_heatmap": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, ctypes.c_double, _c_int, _c_vp, _c_vp]),
+    "bfhip_gaussian_focal_loss_workspace_bytes": (_c_sz, [ctypes.c_longlong]),
+    "bfhip_gaussian_focal_loss": (_c_int, [_c_vp, _c_vp, ctypes.c_longlong, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_query_losses": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 4),
 }
 
 _lib = None
@@ -90,6 +99,16 @@ def check(rc, what):
     if rc != 0:
         msg = load().bfhip_last_error().decode("utf-8", "replace")
         raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def call(name, *args):
+    """Invoke an `int`-returning entry point and raise RuntimeError(bfhip_last_error()) on failure."""
+    check(getattr(load(), name)(*args), name)
+
+
+def call_size(name, *args):
+    """Invoke a *_workspace_bytes() query."""
+    return int(getattr(load(), name)(*args))
 
 
 def ptr(t):

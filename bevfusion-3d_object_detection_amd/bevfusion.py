@@ -177,10 +177,31 @@ class BEVFusion(nn.Module):
         x = self.pts_neck(x)
         return x, depth_loss
 
-    def forward(self, batch_inputs_dict, batch_input_metas=None):
+    def forward(self, batch_inputs_dict, batch_input_metas=None, batch_data_samples=None):
+        """With `batch_data_samples` (ground truth) this is `loss` (one entry point for DDP); otherwise the head
+        outputs and the depth loss."""
+        if batch_data_samples is not None:
+            return self.loss(batch_inputs_dict, batch_data_samples)
         feats, depth_loss = self.extract_feat(batch_inputs_dict, batch_input_metas)
         outs = self.bbox_head(feats, batch_input_metas) if self.bbox_head is not None else feats
         return outs, depth_loss
+
+    def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):
+        """BF/bevfusion.py:387-401: dict of the head's losses (the depth loss is computed but not added, :392)."""
+        metas = [getattr(d, "metainfo", None) for d in batch_data_samples]
+        feats, _ = self.extract_feat(batch_inputs_dict, metas)
+        return dict(self.bbox_head.loss(feats, batch_data_samples))
+
+    def predict(self, batch_inputs_dict, batch_data_samples=None, **kwargs):
+        """BF/bevfusion.py:257-303 without the Det3DDataSample packaging: one dict of boxes/scores/labels per sample."""
+        metas = [getattr(d, "metainfo", None) for d in (batch_data_samples or [])] or None
+        feats, _ = self.extract_feat(batch_inputs_dict, metas)
+        return self.bbox_head.predict(feats, metas)
+
+    @staticmethod
+    def parse_losses(losses):
+        """BF/bevfusion.py:83-120 minus the logging all-reduce: total = sum of every entry whose key contains 'loss'."""
+        return sum(v.mean() for k, v in losses.items() if "loss" in k)
 
 
 def nuscenes_config(camera=True, lidar=True):
@@ -202,7 +223,25 @@ def nuscenes_config(camera=True, lidar=True):
                                           cross_attn_cfg=dict(embed_dims=128, num_heads=8, dropout=0.1),
                                           ffn_cfg=dict(embed_dims=128, feedforward_channels=256, num_fcs=2, ffn_drop=0.1),
                                           pos_encoding_cfg=dict(input_channel=2, num_pos_feats=128)),
-                       common_heads=dict(center=[2, 2], height=[1, 2], dim=[3, 2], rot=[2, 2], vel=[2, 2])),
+                       common_heads=dict(center=[2, 2], height=[1, 2], dim=[3, 2], rot=[2, 2], vel=[2, 2]),
+                       train_cfg=dict(dataset="nuScenes", point_cloud_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0],
+                                      grid_size=[1440, 1440, 41], voxel_size=[0.075, 0.075, 0.2], out_size_factor=8,
+                                      gaussian_overlap=0.1, min_radius=2, pos_weight=-1,
+                                      code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2],
+                                      assigner=dict(type="HungarianAssigner3D",
+                                                    iou_calculator=dict(type="BboxOverlaps3D", coordinate="lidar"),
+                                                    cls_cost=dict(type="mmdet.FocalLossCost", gamma=2.0, alpha=0.25, weight=0.15),
+                                                    reg_cost=dict(type="BBoxBEVL1Cost", weight=0.25),
+                                                    iou_cost=dict(type="IoU3DCost", weight=0.25))),
+                       test_cfg=dict(dataset="nuScenes", grid_size=[1440, 1440, 41], out_size_factor=8,
+                                     voxel_size=[0.075, 0.075], pc_range=[-54.0, -54.0], nms_type=None),
+                       bbox_coder=dict(type="TransFusionBBoxCoder", pc_range=[-54.0, -54.0],
+                                       post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.0,
+                                       out_size_factor=8, voxel_size=[0.075, 0.075], code_size=10),
+                       loss_cls=dict(type="mmdet.FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean",
+                                     loss_weight=1.0),
+                       loss_heatmap=dict(type="mmdet.GaussianFocalLoss", reduction="mean", loss_weight=1.0),
+                       loss_bbox=dict(type="mmdet.L1Loss", reduction="mean", loss_weight=0.25)),
     )
     if lidar:
         cfg["pts_middle_encoder"] = dict(
@@ -229,7 +268,7 @@ def surrogate_loss(outs, depth_loss=0.0):
     (CPU + scipy in the reference, BF/utils.py:241-284) and GT boxes: a Gaussian-focal style term on the
     dense heat-map plus L1 terms on every regression head, so that backward reaches every parameter the
     real loss reaches.  Used by bench.py only; not a training objective."""
-    res = outs[0]
+    res = outs[0][0]
     hm = res["dense_heatmap"].float().sigmoid().clamp(1e-4, 1 - 1e-4)
     loss = -(torch.log(1 - hm) * hm.pow(2)).mean()
     for key in ("center", "height", "dim", "rot", "vel", "heatmap"):

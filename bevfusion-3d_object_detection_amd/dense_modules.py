@@ -259,8 +259,25 @@ class BEVFusionHead(nn.Module):
     def __init__(self, num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
                  num_decoder_layers=1, decoder_layer=dict(), num_heads=8, nms_kernel_size=3, bn_momentum=0.1,
                  common_heads=dict(center=[2, 2], height=[1, 2], dim=[3, 2], rot=[2, 2], vel=[2, 2]),
-                 num_heatmap_convs=2, grid_size=(1440, 1440, 41), out_size_factor=8, **kwargs):
+                 num_heatmap_convs=2, grid_size=(1440, 1440, 41), out_size_factor=8, train_cfg=None, test_cfg=None,
+                 bbox_coder=None,
+                 loss_cls=dict(type="mmdet.FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=1.0),
+                 loss_bbox=dict(type="mmdet.L1Loss", reduction="mean", loss_weight=0.25),
+                 loss_heatmap=dict(type="mmdet.GaussianFocalLoss", reduction="mean", loss_weight=1.0), **kwargs):
         super().__init__()
+        from .head_targets import TransFusionBBoxCoder, _assigner_weights
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.loss_cls_cfg, self.loss_bbox_cfg, self.loss_heatmap_cfg = dict(loss_cls), dict(loss_bbox), dict(loss_heatmap)
+        if train_cfg is not None:
+            grid_size, out_size_factor = train_cfg["grid_size"], train_cfg["out_size_factor"]
+            assert train_cfg["assigner"]["type"] == "HungarianAssigner3D", "only the Hungarian assigner is implemented"
+            self.assign_weights = _assigner_weights(train_cfg["assigner"])
+        if bbox_coder is not None:
+            bc = dict(bbox_coder)
+            bc.pop("type", None)
+            self.bbox_coder = TransFusionBBoxCoder(**bc)
+        else:
+            self.bbox_coder = None
         self.num_classes, self.num_proposals = num_classes, num_proposals
         self.num_decoder_layers, self.nms_kernel_size, self.auxiliary = num_decoder_layers, nms_kernel_size, auxiliary
         self.shared_conv = nn.Conv2d(in_channels, hidden_channel, 3, padding=1)
@@ -310,4 +327,96 @@ class BEVFusionHead(nn.Module):
         rets[0]["query_heatmap_score"] = heatmap.gather(index=top_index[:, None, :].expand(-1, self.num_classes, -1), dim=-1)
         rets[0]["dense_heatmap"] = dense_heatmap
         rets[0]["query_labels"] = top_class
-        return rets
+        self.query_labels = top_class
+        if not self.auxiliary:
+            return ([rets[-1]],)
+        # all decoder layers concatenated along the proposal axis (BF/bevfusion_head.py:292-299)
+        keep = ("dense_heatmap", "dense_heatmap_old", "query_heatmap_score", "query_labels")
+        new_res = {k: (rets[0][k] if k in keep else (torch.cat([r[k] for r in rets], dim=-1) if len(rets) > 1 else rets[0][k]))
+                   for k in rets[0]}
+        return ([new_res],)
+
+    # ------------------------------------------------------------------ targets and losses
+    def get_targets(self, batch_gt_instances_3d, preds_dict):
+        """BF/bevfusion_head.py:450-674 for the whole batch on the device (csrc/head.hip): decode, three matching costs,
+        Hungarian assignment per decoder layer, target scatter, dense heat-map.  `preds_dict` is the (single) dict of
+        forward().  Returns labels i32[B, L*P], label_weights, bbox_targets, bbox_weights, ious, num_pos (host int),
+        matched_ious (0-dim device tensor), heatmap f32[B, C, Y', X'].  No device->host read."""
+        from . import head_targets as ht
+        tc = self.train_cfg
+        dev = preds_dict["center"].device
+        gt_boxes, gt_labels, n_gt, counts = ht.pack_gt(batch_gt_instances_3d, dev)
+        P = self.num_proposals
+        L = self.num_decoder_layers if self.auxiliary else 1
+        vel = preds_dict.get("vel")
+        outs = []
+        for layer in range(L):
+            boxes = self.bbox_coder.decode_boxes(preds_dict["rot"], preds_dict["dim"], preds_dict["center"],
+                                                 preds_dict["height"], vel, p_off=layer * P, num=P)
+            assigned, iou, _, _ = ht.assign_batch(boxes, preds_dict["heatmap"], gt_boxes, gt_labels, n_gt,
+                                                  tc["point_cloud_range"], self.assign_weights, p_off=layer * P)
+            outs.append(ht.build_targets(assigned, iou, gt_boxes, gt_labels, self.num_classes, self.bbox_coder.code_size,
+                                         tc["point_cloud_range"], tc["out_size_factor"], tc["voxel_size"],
+                                         tc.get("pos_weight", -1)))
+        labels, label_weights, bbox_targets, bbox_weights, ious = [torch.cat(x, dim=1) if L > 1 else x[0] for x in zip(*outs)]
+        pos_per_sample = [min(c, P) * L for c in counts]  # the Hungarian step matches min(#GT, #proposals) pairs
+        num_pos = sum(pos_per_sample)
+        denom = torch.tensor([max(n, 1) for n in pos_per_sample], dtype=torch.float32).to(dev, non_blocking=True)
+        matched_ious = (ious.sum(1) / denom).mean()
+        heatmap = ht.draw_heatmap(gt_boxes, gt_labels, n_gt, self.num_classes, tc["grid_size"], tc["point_cloud_range"],
+                                  tc["voxel_size"], tc["out_size_factor"], tc["gaussian_overlap"], tc["min_radius"])
+        return labels, label_weights, bbox_targets, bbox_weights, ious, num_pos, matched_ious, heatmap
+
+    def loss_by_feat(self, preds_dicts, batch_gt_instances_3d, *args, **kwargs):
+        """BF/bevfusion_head.py:696-796."""
+        from . import head_targets as ht
+        preds_dict = preds_dicts[0][0]
+        (labels, label_weights, bbox_targets, bbox_weights, ious, num_pos, matched_ious,
+         heatmap) = self.get_targets(batch_gt_instances_3d, preds_dict)
+        loss_dict = dict()
+        loss_dict["loss_heatmap"] = ht.gaussian_focal_loss_with_logits(
+            preds_dict["dense_heatmap"], heatmap, 1e-4, self.loss_heatmap_cfg.get("loss_weight", 1.0))
+        P = self.num_proposals
+        L = self.num_decoder_layers if self.auxiliary else 1
+        keys = ["center", "height", "dim", "rot"] + (["vel"] if "vel" in preds_dict else [])
+        preds = torch.cat([preds_dict[k] for k in keys], dim=1)  # [B, code_size, L*P]
+        code_weights = self.train_cfg.get("code_weights", None) or [1.0] * preds.shape[1]
+        cw = getattr(self, "_code_weights", None)
+        if cw is None or cw.device != preds.device:
+            cw = self._code_weights = torch.tensor(code_weights[:preds.shape[1]], dtype=torch.float32).to(preds.device)
+        avg = float(max(num_pos, 1))
+        for layer in range(L):
+            prefix = "layer_-1" if (layer == self.num_decoder_layers - 1 or (layer == 0 and not self.auxiliary)) else f"layer_{layer}"
+            sl = slice(layer * P, (layer + 1) * P)
+            cls_sum, box_sum = ht.query_losses(preds_dict["heatmap"], preds, labels[:, sl], label_weights[:, sl],
+                                               bbox_targets[:, sl], bbox_weights[:, sl], cw, layer * P, P,
+                                               self.loss_cls_cfg.get("gamma", 2.0), self.loss_cls_cfg.get("alpha", 0.25))
+            loss_dict[f"{prefix}_loss_cls"] = cls_sum / avg * self.loss_cls_cfg.get("loss_weight", 1.0)
+            loss_dict[f"{prefix}_loss_bbox"] = box_sum / avg * self.loss_bbox_cfg.get("loss_weight", 1.0)
+        loss_dict["matched_ious"] = matched_ious
+        return loss_dict
+
+    def loss(self, batch_feats, batch_data_samples):
+        """BF/bevfusion_head.py:676-694.  `batch_data_samples`: objects with `.gt_instances_3d` (+ `.metainfo`), or the
+        ground truth itself as (boxes, labels) pairs."""
+        gts = [getattr(d, "gt_instances_3d", d) for d in batch_data_samples]
+        metas = [getattr(d, "metainfo", None) for d in batch_data_samples]
+        return self.loss_by_feat(self(batch_feats, metas), gts)
+
+    def predict_by_feat(self, preds_dicts, metas=None, img=None, rescale=False, for_roi=False):
+        """BF/bevfusion_head.py:322-448 with nms_type None (the nuScenes configs): score = sigmoid(cls) * heat-map score
+        of the query's own class, decode with the score / centre-range filter.  One dict per sample."""
+        preds = preds_dicts[0][0]
+        P = self.num_proposals
+        score = preds["heatmap"][..., -P:].sigmoid()
+        one_hot = F.one_hot(self.query_labels, num_classes=self.num_classes).permute(0, 2, 1)
+        score = score * preds["query_heatmap_score"] * one_hot
+        vel = preds["vel"][..., -P:] if "vel" in preds else None
+        nms_type = (self.test_cfg or {}).get("nms_type", None)
+        assert nms_type is None, "only nms_type=None (the reference's nuScenes setting) is implemented"
+        rets = self.bbox_coder.decode(score, preds["rot"][..., -P:], preds["dim"][..., -P:], preds["center"][..., -P:],
+                                      preds["height"][..., -P:], vel, filter=True)
+        return [dict(bboxes_3d=r["bboxes"], scores_3d=r["scores"], labels_3d=r["labels"].int()) for r in rets]
+
+    def predict(self, batch_feats, batch_input_metas=None):
+        return self.predict_by_feat(self(batch_feats, batch_input_metas), batch_input_metas)

@@ -283,6 +283,57 @@ int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x, const float 
                    int C, int relu, float *dx, float *dres, float *dgb, void *workspace, size_t workspace_bytes,
                    void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * TransFusion head: box decoding, target assignment and losses on the device  (SURVEY 8 f-3).
+ *   Replaces TransFusionBBoxCoder.decode/encode (BF/utils.py:33-96), HungarianAssigner3D.assign with its three costs
+ *   and the `.cpu()` + scipy.optimize.linear_sum_assignment round trip (BF/utils.py:128-151,241-284; IoU as
+ *   mmdet3d/structures/bbox_3d/base_box3d.py:529-590), the target scatter and the box-by-box heat-map drawing of
+ *   BEVFusionHead.get_targets_single (BF/bevfusion_head.py:514-674, mmdet3d/models/utils/gaussian.py:9-92) and the
+ *   three loss terms of loss_by_feat (:696-796: mmdet GaussianFocalLoss / FocalLoss / L1Loss).
+ *   Head outputs keep the reference layout [B, channels, ld] (ld = proposals of all decoder layers concatenated);
+ *   one call handles the P proposals starting at p_off.  Ground truth is padded to G boxes per sample:
+ *   gt_boxes f32[B,G,Wg] = (x, y, z_bottom, dx, dy, dz, yaw[, vx, vy]), gt_labels i32[B,G], n_gt i32[B].
+ *
+ *   decode_boxes   cfg_host = {out_size_factor, voxel_x, voxel_y, pc_x0, pc_y0}; vel may be NULL (-> 7 columns);
+ *                  boxes f32[B,P,7|9] bottom-centre
+ *   assign_cost    cfg_host = {cls_weight, alpha, gamma, eps, reg_weight, iou_weight, pc_x0, pc_y0, pc_x1, pc_y1};
+ *                  cost, iou f32[B,P,G] (columns >= n_gt[b] are written as 0 and never read)
+ *   hungarian      minimum-cost assignment per sample, fp64, max(P, G) <= 1024.  assigned i32[B,P]: 0 = background,
+ *                  g + 1 = matched (AssignResult.gt_inds); status i32[B]: 0 ok, 1 = non-finite costs (all background)
+ *   assign_targets cfg_host = {pc_x0, pc_y0, (float)(out_size_factor*voxel_x), (float)(out_size_factor*voxel_y),
+ *                  pos_weight}; labels i32[B,P] (num_classes = background), label_weights f32[B,P],
+ *                  bbox_targets / bbox_weights f32[B,P,code_size], ious f32[B,P] (clamped matched IoU)
+ *   draw_heatmap   cfg_host = {pc_x0, pc_y0, voxel_x, voxel_y, out_size_factor}; heatmap f32[B,num_classes,H,W] is
+ *                  cleared and drawn; box (x, y) lands at [cls][x cell][y cell] (the `center_int[[1, 0]]` fix, :662)
+ *   gaussian_focal_loss  loss_sum_npos f32[2] <- (sum of element losses on clip_sigmoid(logits), count of target == 1);
+ *                  grad f32[n] <- d element loss / d logit (unscaled)
+ *   query_losses   loss_sums f32[2] <- (weighted focal sum over [B,P,C], weighted L1 sum over [B,P,K]); grad_cls /
+ *                  grad_box in the layout of the inputs (entries outside [p_off, p_off+P) untouched)
+ * --------------------------------------------------------------------------------------- */
+int bfhip_decode_boxes(const float *center, const float *height, const float *dim, const float *rot,
+                       const float *vel, int B, int P, int ld, int p_off, const float *cfg_host, float *boxes,
+                       void *stream);
+int bfhip_assign_cost(const float *boxes, int W, const float *cls_logits, int C, int ld, int p_off,
+                      const float *gt_boxes, int Wg, const int32_t *gt_labels, const int32_t *n_gt, int B, int P,
+                      int G, const float *cfg_host, float *cost, float *iou, void *stream);
+int bfhip_hungarian(const float *cost, const int32_t *n_gt, int B, int P, int G, int32_t *assigned,
+                    int32_t *status, void *stream);
+int bfhip_assign_targets(const int32_t *assigned, const float *iou, const float *gt_boxes, int Wg,
+                         const int32_t *gt_labels, int B, int P, int G, int num_classes, int code_size,
+                         const float *cfg_host, int32_t *labels, float *label_weights, float *bbox_targets,
+                         float *bbox_weights, float *ious, void *stream);
+int bfhip_draw_heatmap(const float *gt_boxes, int Wg, const int32_t *gt_labels, const int32_t *n_gt, int B, int G,
+                       int num_classes, int H, int W, const float *cfg_host, double gaussian_overlap,
+                       int min_radius, float *heatmap, void *stream);
+size_t bfhip_gaussian_focal_loss_workspace_bytes(long long n);
+int bfhip_gaussian_focal_loss(const float *logits, const float *target, long long n, float clip_eps,
+                              float *loss_sum_npos, float *grad, void *workspace, size_t workspace_bytes,
+                              void *stream);
+int bfhip_query_losses(const float *cls_logits, const int32_t *labels, const float *label_weights,
+                       const float *box_pred, const float *bbox_targets, const float *bbox_weights,
+                       const float *code_weights, int B, int C, int P, int K, int ld, int p_off, float gamma,
+                       float alpha, float *grad_cls, float *grad_box, float *loss_sums, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
