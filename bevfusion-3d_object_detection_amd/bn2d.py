@@ -1,0 +1,121 @@
+"""BatchNorm2d (+ residual) (+ ReLU) for the dense conv stacks, fused in csrc/bn2d.hip when the activation is
+channels-last (the layout MIOpen's NHWC kernels produce) and the module is training.
+
+`BatchNorm2dAct` IS an `nn.BatchNorm2d` (same parameters, buffers and state-dict keys as the reference's
+`build_norm_layer(dict(type='BN'))` modules), so checkpoints load unchanged; `bn_act()` returns the
+`[BatchNorm2dAct(act=True), nn.Identity()]` pair that replaces `[BatchNorm2d, ReLU]` inside an `nn.Sequential`
+without shifting the indices of the following layers.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+FUSED_BN2D = os.environ.get("BFHIP_FUSED_BN2D", "1") == "1"  # A/B switch; the torch path has identical semantics
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 22), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+class _BN2dFunction(torch.autograd.Function):
+    """y = act(BN_train(x) [+ residual]); x, residual, y channels-last [N, C, H, W], f32 or bf16."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu):
+        N, C, H, W = x.shape
+        M, dt = N * H * W, _DT[x.dtype]
+        res = None
+        if residual is not None:
+            res = residual if residual.dtype == x.dtype else residual.to(x.dtype)
+            res = res.contiguous(memory_format=torch.channels_last)
+        y = torch.empty_like(x)  # keeps the channels-last strides
+        stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        nbytes = _lib.call_size("bfhip_bn2d_workspace_bytes", M, C, dt)
+        ws = _workspace(x.device, nbytes)
+        _lib.call("bfhip_bn2d_fwd", _lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), M, C, dt, float(eps),
+                  float(momentum), 1 if relu else 0, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(stats),
+                  _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
+        keep_y = relu and residual is not None  # otherwise the ReLU mask is recomputed from x in the backward
+        ctx.save_for_backward(x, y if keep_y else None, stats, weight)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.res_dtype = residual.dtype if residual is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, stats, weight = ctx.saved_tensors
+        N, C, H, W = x.shape
+        M, dt = N * H * W, _DT[x.dtype]
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgb = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        nbytes = _lib.call_size("bfhip_bn2d_workspace_bytes", M, C, dt)
+        ws = _workspace(x.device, nbytes)
+        _lib.call("bfhip_bn2d_bwd", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(weight), M, C, dt,
+                  1 if ctx.relu else 0, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgb), _lib.ptr(ws), ws.numel(),
+                  _lib.stream_of(x))
+        if dres is not None and ctx.res_dtype != dres.dtype:
+            dres = dres.to(ctx.res_dtype)
+        return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None
+
+
+class BatchNorm2dAct(nn.BatchNorm2d):
+    """nn.BatchNorm2d whose forward can also add a residual and apply ReLU (`act=True` makes ReLU the default, for use
+    inside nn.Sequential).  `num_batches_tracked` is advanced lazily (it only matters when momentum is None): the
+    per-step `add_(1)` launch of every BN layer is folded into a host counter that is flushed into the buffer
+    whenever the state dict is read."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, act=False, **kw):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats,
+                         **kw)
+        self.act = act
+        self._pending_batches = 0
+
+    def _flush_batches(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._pending_batches)
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_batches()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def fusable(self, x):
+        return (FUSED_BN2D and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine
+                and self.track_running_stats and self.momentum is not None and x.numel() > x.shape[1]
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and _lib.call_size("bfhip_bn2d_supported", x.numel() // x.shape[1], x.shape[1], _DT[x.dtype]) == 1)
+
+    def forward(self, x, residual=None, relu=None):
+        relu = self.act if relu is None else relu
+        if self.fusable(x):
+            self._pending_batches += 1
+            return _BN2dFunction.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                       self.momentum, relu)
+        self._flush_batches()
+        out = super().forward(x)
+        if residual is not None:
+            out = out + residual
+        return F.relu(out) if relu else out
+
+    def extra_repr(self):
+        return super().extra_repr() + (", act=ReLU" if self.act else "")
+
+
+def bn_act(num_features, eps=1e-5, momentum=0.1):
+    """[BN + ReLU fused, placeholder] in place of [BatchNorm2d, ReLU] of an nn.Sequential (indices preserved)."""
+    return [BatchNorm2dAct(num_features, eps=eps, momentum=momentum, act=True), nn.Identity()]

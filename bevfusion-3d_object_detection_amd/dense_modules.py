@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .bn2d import BatchNorm2dAct, bn_act
 from .registry import MODELS
 
 
@@ -27,20 +28,19 @@ class _Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2dAct(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2dAct(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = BatchNorm2dAct(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=identity, relu=True)  # BN + identity + ReLU in one pass
 
 
 @MODELS.register_module()
@@ -51,7 +51,7 @@ class ResNet50(nn.Module):
         super().__init__()
         self.out_indices = out_indices
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BatchNorm2dAct(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
         self.inplanes = 64
@@ -64,14 +64,14 @@ class ResNet50(nn.Module):
         down = None
         if stride != 1 or self.inplanes != planes * 4:
             down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
-                                 nn.BatchNorm2d(planes * 4))
+                                 BatchNorm2dAct(planes * 4))
         layers = [_Bottleneck(self.inplanes, planes, stride, down)]
         self.inplanes = planes * 4
         layers += [_Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         outs = []
         for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             x = layer(x)
@@ -82,9 +82,11 @@ class ResNet50(nn.Module):
 
 def _conv_module(cin, cout, k, padding=0, norm=True, act=True, eps=1e-5, momentum=0.1, stride=1):
     layers = [nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=not norm)]
-    if norm:
-        layers.append(nn.BatchNorm2d(cout, eps=eps, momentum=momentum))
-    if act:
+    if norm and act:
+        layers += bn_act(cout, eps=eps, momentum=momentum)
+    elif norm:
+        layers.append(BatchNorm2dAct(cout, eps=eps, momentum=momentum))
+    elif act:
         layers.append(nn.ReLU(inplace=True))
     return nn.Sequential(*layers)
 
@@ -125,7 +127,7 @@ class ConvFuser(nn.Sequential):
     def __init__(self, in_channels, out_channels):
         self.in_channels, self.out_channels = in_channels, out_channels
         super().__init__(nn.Conv2d(sum(in_channels), out_channels, 3, padding=1, bias=False),
-                         nn.BatchNorm2d(out_channels), nn.ReLU(True))
+                         *bn_act(out_channels))
 
     def forward(self, inputs):
         return super().forward(torch.cat(inputs, dim=1))
@@ -142,10 +144,10 @@ class SECOND(nn.Module):
         blocks = []
         for i, n in enumerate(layer_nums):
             block = [nn.Conv2d(in_filters[i], out_channels[i], 3, stride=layer_strides[i], padding=1, bias=False),
-                     nn.BatchNorm2d(out_channels[i], eps=eps, momentum=mom), nn.ReLU(inplace=True)]
+                     *bn_act(out_channels[i], eps=eps, momentum=mom)]
             for _ in range(n):
                 block += [nn.Conv2d(out_channels[i], out_channels[i], 3, padding=1, bias=False),
-                          nn.BatchNorm2d(out_channels[i], eps=eps, momentum=mom), nn.ReLU(inplace=True)]
+                          *bn_act(out_channels[i], eps=eps, momentum=mom)]
             blocks.append(nn.Sequential(*block))
         self.blocks = nn.ModuleList(blocks)
 
@@ -172,7 +174,7 @@ class SECONDFPN(nn.Module):
             else:
                 k = int(round(1 / s))
                 up = nn.Conv2d(in_channels[i], oc, k, stride=k, bias=False)
-            deblocks.append(nn.Sequential(up, nn.BatchNorm2d(oc, eps=eps, momentum=mom), nn.ReLU(inplace=True)))
+            deblocks.append(nn.Sequential(up, *bn_act(oc, eps=eps, momentum=mom)))
         self.deblocks = nn.ModuleList(deblocks)
 
     def forward(self, x):
@@ -282,8 +284,8 @@ class BEVFusionHead(nn.Module):
         self.num_decoder_layers, self.nms_kernel_size, self.auxiliary = num_decoder_layers, nms_kernel_size, auxiliary
         self.shared_conv = nn.Conv2d(in_channels, hidden_channel, 3, padding=1)
         self.heatmap_head = nn.Sequential(
-            nn.Conv2d(hidden_channel, hidden_channel, 3, padding=1, bias=False), nn.BatchNorm2d(hidden_channel),
-            nn.ReLU(inplace=True), nn.Conv2d(hidden_channel, num_classes, 3, padding=1))
+            nn.Conv2d(hidden_channel, hidden_channel, 3, padding=1, bias=False), *bn_act(hidden_channel),
+            nn.Conv2d(hidden_channel, num_classes, 3, padding=1))
         self.class_encoding = nn.Conv1d(num_classes, hidden_channel, 1)
         self.decoder = nn.ModuleList([TransformerDecoderLayer(**decoder_layer) for _ in range(num_decoder_layers)])
         heads = dict(common_heads)

@@ -284,6 +284,25 @@ int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x, const float 
                    void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * BatchNorm2d (+ residual) (+ ReLU), training mode, on channels-last activations viewed as [M = N*H*W, C]
+ *   (the BN / add / ReLU after every dense conv: ResNet bottlenecks, BF/depth_lss.py:581-620,
+ *    BF/bevfusion_head.py:25-38,104-126, mmdet3d/models/backbones/second.py:70-95, necks/second_fpn.py:60-84)
+ *   dtype: 0 = f32, 1 = bf16 (x, residual, y, dy, dx, dres share it); gamma/beta/stats/running stats are f32.
+ *   C must be a multiple of the 16-byte vector (4 f32 / 8 bf16) with at most 256 vectors per row:
+ *   bfhip_bn2d_supported() tells.  stats f32[4C] <- (mean, invstd, a = gamma*invstd, b = beta - mean*a).
+ *   bwd: pass y only for layers that added a residual before the ReLU (otherwise the ReLU mask is recomputed
+ *   from x and y may be NULL); dgb f32[2C] <- (dgamma, dbeta); dres optional.
+ * --------------------------------------------------------------------------------------- */
+int bfhip_bn2d_supported(long long M, int C, int dtype);
+size_t bfhip_bn2d_workspace_bytes(long long M, int C, int dtype);
+int bfhip_bn2d_fwd(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
+                   int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
+                   float *stats, void *y, void *workspace, size_t workspace_bytes, void *stream);
+int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma, long long M,
+                   int C, int dtype, int relu, void *dx, void *dres, float *dgb, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * TransFusion head: box decoding, target assignment and losses on the device  (SURVEY 8 f-3).
  *   Replaces TransFusionBBoxCoder.decode/encode (BF/utils.py:33-96), HungarianAssigner3D.assign with its three costs
  *   and the `.cpu()` + scipy.optimize.linear_sum_assignment round trip (BF/utils.py:128-151,241-284; IoU as

@@ -1,0 +1,100 @@
+"""GPU: fused BatchNorm2d(+residual)(+ReLU) on channels-last activations (csrc/bn2d.hip) against torch's own
+batch_norm / add / relu in fp32 on the same inputs.  Tolerances: fp32 1e-4 (max-normalised); bf16 storage 1e-2."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import bevfusion_amd  # noqa: F401
+from bevfusion_amd import bn2d
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, res, bn, relu):
+    """fp32 torch reference with autograd."""
+    x32 = x.detach().float().requires_grad_(True)
+    r32 = res.detach().float().requires_grad_(True) if res is not None else None
+    w = bn.weight.detach().clone().requires_grad_(True)
+    b = bn.bias.detach().clone().requires_grad_(True)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    y = F.batch_norm(x32, rm, rv, w, b, True, bn.momentum, bn.eps)
+    if r32 is not None:
+        y = y + r32
+    if relu:
+        y = F.relu(y)
+    return x32, r32, w, b, rm, rv, y
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("shape", [(6, 64, 33, 47), (2, 8, 64, 176), (3, 80, 19, 21), (2, 2048, 8, 22), (5, 256, 20, 20), (1, 32, 7, 5), (2, 328, 9, 11)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False), (True, False)])
+def test_bn2d_matches_torch(dev, dtype, tol, shape, res, relu):
+    torch.manual_seed(0)
+    N, C, H, W = shape
+    x = (torch.randn(shape, device=dev) * 1.7 + 0.4).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r = torch.randn(shape, device=dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
+    bn = bn2d.BatchNorm2dAct(C, eps=1e-3, momentum=0.05).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    x32, r32, w, b, rm, rv, yref = _ref(x, r, bn, relu)
+    assert bn.fusable(x)
+    y = bn(x, residual=r, relu=relu)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel(y.float(), yref) < tol
+    assert rel(bn.running_mean, rm) < 1e-4 and rel(bn.running_var, rv) < 1e-4
+    g = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    y.backward(g.to(dtype))
+    yref.backward(g.to(dtype).float())
+    assert rel(x.grad.float(), x32.grad) < tol
+    assert rel(bn.weight.grad, w.grad) < tol and rel(bn.bias.grad, b.grad) < tol
+    if res:
+        assert rel(r.grad.float(), r32.grad) < tol
+
+
+def test_relu_mask_recomputed_from_x_equals_mask_from_y(dev):
+    """Without a residual the backward recomputes the ReLU mask from x; it must zero exactly the entries that are 0 in y."""
+    torch.manual_seed(1)
+    x = torch.randn(4, 64, 30, 30, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bn = bn2d.BatchNorm2dAct(64, act=True).to(dev).train()
+    y = bn(x)
+    y.backward(torch.ones_like(y))
+    z = torch.zeros_like(x).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    # with dy = 1 and the same mask, a residual input's gradient IS the mask
+    bn2 = bn2d.BatchNorm2dAct(64, act=True).to(dev).train()
+    y2 = bn2(x.detach(), residual=z)
+    y2.backward(torch.ones_like(y2))
+    assert torch.equal(y, y2)
+    assert torch.equal(z.grad > 0, y > 0)
+    assert torch.equal(bn.bias.grad, bn2.bias.grad)  # dbeta = sum of the masked gradient: same mask both ways
+
+
+def test_unsupported_shapes_fall_back(dev):
+    bn = bn2d.BatchNorm2dAct(6, act=True).to(dev).train()
+    x = torch.randn(2, 6, 5, 5, device=dev).contiguous(memory_format=torch.channels_last)
+    assert not bn.fusable(x)               # 6 channels: not a multiple of the 16-byte vector
+    y = bn(x)
+    assert torch.allclose(y, F.relu(F.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.1, bn.eps)), atol=1e-5)
+    bn64 = bn2d.BatchNorm2dAct(64, act=True).to(dev).train()
+    xc = torch.randn(2, 64, 5, 5, device=dev)   # NCHW-contiguous: not channels-last
+    assert not bn64.fusable(xc)
+    assert bn64.eval()(xc.contiguous(memory_format=torch.channels_last)).shape == xc.shape  # eval: torch path
+    assert int(bn64.num_batches_tracked) == 0
+    bn64.train()(xc.contiguous(memory_format=torch.channels_last))
+    assert int(bn64.state_dict()["num_batches_tracked"]) == 1  # lazy counter flushed when the state dict is read
+
+
+def test_resnet_block_state_dict_keys(dev):
+    from bevfusion_amd.dense_modules import ResNet50, SECOND
+    keys = set(ResNet50().state_dict().keys())
+    for k in ("conv1.weight", "bn1.running_var", "layer1.0.bn3.weight", "layer1.0.downsample.1.num_batches_tracked",
+              "layer4.2.conv3.weight"):
+        assert k in keys, k
+    sk = set(SECOND(256, [128, 256], [5, 5], [1, 2]).state_dict().keys())
+    assert "blocks.0.1.weight" in sk and "blocks.0.3.weight" in sk and "blocks.1.16.running_mean" in sk
