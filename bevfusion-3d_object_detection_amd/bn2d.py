@@ -73,17 +73,11 @@ class _BN2dFunction(torch.autograd.Function):
         return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None
 
 
-class BatchNorm2dAct(nn.BatchNorm2d):
-    """nn.BatchNorm2d whose forward can also add a residual and apply ReLU (`act=True` makes ReLU the default, for use
-    inside nn.Sequential).  `num_batches_tracked` is advanced lazily (it only matters when momentum is None): the
-    per-step `add_(1)` launch of every BN layer is folded into a host counter that is flushed into the buffer
-    whenever the state dict is read."""
+class _LazyBatchCounter:
+    """`num_batches_tracked` advanced lazily (it only matters when momentum is None): the per-step `add_(1)` launch of every
+    BN layer is folded into a host counter that is flushed into the buffer whenever the state dict is read."""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, act=False, **kw):
-        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats,
-                         **kw)
-        self.act = act
-        self._pending_batches = 0
+    _pending_batches = 0
 
     def _flush_batches(self):
         if self._pending_batches and self.num_batches_tracked is not None:
@@ -93,6 +87,16 @@ class BatchNorm2dAct(nn.BatchNorm2d):
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         self._flush_batches()
         super()._save_to_state_dict(destination, prefix, keep_vars)
+
+
+class BatchNorm2dAct(_LazyBatchCounter, nn.BatchNorm2d):
+    """nn.BatchNorm2d whose forward can also add a residual and apply ReLU (`act=True` makes ReLU the default, for use
+    inside nn.Sequential)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, act=False, **kw):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats,
+                         **kw)
+        self.act = act
 
     def fusable(self, x):
         return (FUSED_BN2D and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine
@@ -114,6 +118,25 @@ class BatchNorm2dAct(nn.BatchNorm2d):
 
     def extra_repr(self):
         return super().extra_repr() + (", act=ReLU" if self.act else "")
+
+
+class BatchNormRows(_LazyBatchCounter, nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters / buffers / state-dict keys) for row-major feature matrices [M, C]: in training on a
+    supported width the statistics, the affine map and an optional ReLU run in the fused kernels of csrc/bn2d.hip
+    (an [M, C] matrix is the channels-last view [M, C, 1, 1]).  [B, C, L] inputs take the torch path."""
+
+    def forward(self, x, relu=False):
+        if (FUSED_BN2D and self.training and x.is_cuda and x.dim() == 2 and x.dtype in _DT and self.affine
+                and self.track_running_stats and self.momentum is not None and x.shape[0] > 1 and x.is_contiguous()
+                and _lib.call_size("bfhip_bn2d_supported", x.shape[0], x.shape[1], _DT[x.dtype]) == 1):
+            self._pending_batches += 1
+            M, C = x.shape
+            y = _BN2dFunction.apply(x.view(M, C, 1, 1), None, self.weight, self.bias, self.running_mean, self.running_var,
+                                    self.eps, self.momentum, relu)
+            return y.view(M, C)
+        self._flush_batches()
+        out = super().forward(x)
+        return F.relu(out) if relu else out
 
 
 def bn_act(num_features, eps=1e-5, momentum=0.1):

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .bn2d import BatchNorm2dAct, bn_act
+from .bn2d import BatchNorm2dAct, BatchNormRows, bn_act
 from .registry import MODELS
 
 
@@ -184,14 +184,29 @@ class SECONDFPN(nn.Module):
 
 # ----------------------------------------------------------------------------- TransFusion head (forward)
 class PositionEncodingLearned(nn.Module):
+    """Conv1d(k=1) -> BN1d -> ReLU -> Conv1d(k=1) over positions (BF/transformer.py:10-23).  A k=1 Conv1d is a linear map
+    over channels, so the stack is evaluated on the row-major [B*N, C] matrix (`forward_nlc`): the BatchNorm then is a
+    column reduction of a contiguous matrix (fused kernel) instead of a strided [B, C, N] reduction, and the decoder gets
+    the [B, N, C] layout it transposes to anyway.  Parameters and state-dict keys are those of the Conv1d/BN1d stack."""
+
     def __init__(self, input_channel, num_pos_feats=288):
         super().__init__()
         self.position_embedding_head = nn.Sequential(nn.Conv1d(input_channel, num_pos_feats, 1),
-                                                     nn.BatchNorm1d(num_pos_feats), nn.ReLU(inplace=True),
+                                                     BatchNormRows(num_pos_feats), nn.ReLU(inplace=True),
                                                      nn.Conv1d(num_pos_feats, num_pos_feats, 1))
 
+    def forward_nlc(self, xyz):
+        """xyz [B, N, in] -> [B, N, C]."""
+        conv1, bn, _, conv2 = self.position_embedding_head
+        B, N, _ = xyz.shape
+        h = F.linear(xyz.reshape(B * N, -1), conv1.weight[:, :, 0], conv1.bias)
+        h = bn(h.contiguous(), relu=True)
+        h = F.linear(h, conv2.weight[:, :, 0], conv2.bias)
+        return h.view(B, N, -1)
+
     def forward(self, xyz):
-        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+        """xyz [B, N, in] -> [B, C, N] (the reference's layout)."""
+        return self.forward_nlc(xyz).transpose(1, 2)
 
 
 class _MHA(nn.Module):
@@ -227,8 +242,8 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, query, key=None, query_pos=None, key_pos=None):
         """query [B, C, Nq], key [B, C, Nk], *_pos [B, N, 2] -> [B, C, Nq]."""
-        qp = self.self_posembed(query_pos).transpose(1, 2)
-        kp = self.cross_posembed(key_pos).transpose(1, 2)
+        qp = self.self_posembed.forward_nlc(query_pos)
+        kp = self.cross_posembed.forward_nlc(key_pos)
         q, k = query.transpose(1, 2), key.transpose(1, 2)
         q = self.norms[0](self.self_attn(q, q, q + qp, qp, qp))
         q = self.norms[1](self.cross_attn(q, k, k + kp, qp, kp))

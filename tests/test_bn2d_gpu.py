@@ -98,3 +98,27 @@ def test_resnet_block_state_dict_keys(dev):
         assert k in keys, k
     sk = set(SECOND(256, [128, 256], [5, 5], [1, 2]).state_dict().keys())
     assert "blocks.0.1.weight" in sk and "blocks.0.3.weight" in sk and "blocks.1.16.running_mean" in sk
+
+
+def test_position_encoding_rows_equals_conv1d_stack(dev):
+    """PositionEncodingLearned evaluated on the row-major [B*N, C] matrix (fused BN) == the Conv1d/BN1d/ReLU/Conv1d stack of
+    the reference (BF/transformer.py:10-23) built from the same parameters."""
+    from torch import nn
+    from bevfusion_amd.dense_modules import PositionEncodingLearned
+    torch.manual_seed(0)
+    pe = PositionEncodingLearned(2, 128).to(dev).train()
+    ref = nn.Sequential(nn.Conv1d(2, 128, 1), nn.BatchNorm1d(128), nn.ReLU(), nn.Conv1d(128, 128, 1)).to(dev).train()
+    ref.load_state_dict(pe.position_embedding_head.state_dict())
+    xyz = torch.rand(3, 500, 2, device=dev) * 180
+    out = pe(xyz)
+    want = ref(xyz.transpose(1, 2).contiguous())
+    assert out.shape == want.shape == (3, 128, 500)
+    assert rel(out, want) < 1e-4
+    out.square().mean().backward()
+    want.square().mean().backward()
+    for (n, p), (_, q) in zip(pe.position_embedding_head.named_parameters(), ref.named_parameters()):
+        if n == "0.bias":   # a bias in front of a BatchNorm has exactly zero gradient
+            assert float(p.grad.abs().max()) < 1e-8 and float(q.grad.abs().max()) < 1e-8
+            continue
+        assert rel(p.grad, q.grad) < 1e-3, n
+    assert rel(pe.position_embedding_head[1].running_var, ref[1].running_var) < 1e-4
