@@ -174,6 +174,8 @@ class _ModelWorkload:
                 sub = getattr(self.model, name, None)  # 2-D conv stacks only (sparse conv weights are 5-D)
                 if sub is not None:
                     sub.to(memory_format=torch.channels_last)
+        if self.channels_last and getattr(self.model, "pts_middle_encoder", None) is not None:
+            self.model.pts_middle_encoder.bev_channels_last = True  # BEV map handed to the NHWC convs without a relayout
         if self.amp and getattr(self.model, "view_transform", None) is not None:
             self.model.view_transform.conv_dtype = torch.bfloat16  # dense convs bf16, index paths + pooling fp32
         self.model.lidar_side_stream = os.environ.get("BENCH_SIDE_STREAM", "1") == "1"

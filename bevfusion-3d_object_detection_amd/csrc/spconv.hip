@@ -915,6 +915,43 @@ __global__ __launch_bounds__(256) void bev_to_sparse_kernel(const float *__restr
   grad_feats[t] = grad_out[((((size_t)id.x * C + c) * Z + id.w) * X + id.y) * Y + id.z];
 }
 
+// channels-last variants: out[b][x][y][c*Z + z] (the NHWC memory of the [B, C*Z, X, Y] BEV map), f32 or bf16; a sparse row's
+// C channels land in one (Z-interleaved) segment of the pixel instead of C planes X*Y apart
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sparse_to_bev_nhwc_kernel(const float *__restrict__ feats,
+                                                                 const int4 *__restrict__ indices, int N, int C,
+                                                                 int X, int Y, int Z, T *__restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = t / C;
+  int c = (int)(t - n * C);
+  if (n >= N) return;
+  int4 id = indices[n];
+  size_t o = (((size_t)id.x * X + id.y) * Y + id.z) * ((size_t)C * Z) + (size_t)c * Z + id.w;
+  if (sizeof(T) == 2) ((unsigned short *)out)[o] = f32_to_bf16_rne(feats[t]);
+  else ((float *)out)[o] = feats[t];
+}
+
+// grad element (b, ch, x, y) at grad[b*sb + x*sx + y*sy + ch] (channel stride 1; a channel slice of a wider NHWC tensor works)
+template <typename T>
+__global__ __launch_bounds__(256) void bev_nhwc_to_sparse_kernel(const T *__restrict__ grad, long long sb, long long sx,
+                                                                 long long sy, const int4 *__restrict__ indices,
+                                                                 int N, int C, int Z, float *__restrict__ grad_feats) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = t / C;
+  int c = (int)(t - n * C);
+  if (n >= N) return;
+  int4 id = indices[n];
+  size_t o = (size_t)(id.x * sb + id.y * sx + id.z * sy) + (size_t)c * Z + id.w;
+  if (sizeof(T) == 2) grad_feats[t] = __uint_as_float((unsigned)((const unsigned short *)grad)[o] << 16);
+  else grad_feats[t] = ((const float *)grad)[o];
+}
+
 inline unsigned table_cap(int n) {
   unsigned cap = 1024;
   while (cap < 2u * (unsigned)n) cap <<= 1;
@@ -1294,4 +1331,41 @@ BFHIP_EXPORT int bfhip_bev_to_sparse(const float *grad_out, const int32_t *indic
   hipLaunchKernelGGL(bev_to_sparse_kernel, dim3(ceil_div((long long)N * C, 256)), dim3(256), 0, stream, grad_out,
                      (const int4 *)indices, N, C, X, Y, Z, grad_feats);
   return check_launch("bev_to_sparse");
+}
+
+BFHIP_EXPORT int bfhip_sparse_to_bev_nhwc(const float *feats, const int32_t *indices, int N, int C, int B, int X,
+                                          int Y, int Z, int dtype, void *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BFHIP_REQUIRE(N >= 0 && C > 0 && B > 0 && X > 0 && Y > 0 && Z > 0 && out && (dtype == 0 || dtype == 1),
+                "sparse_to_bev_nhwc: bad arguments");
+  const size_t es = dtype == 1 ? 2 : 4;
+  if (hipMemsetAsync(out, 0, (size_t)B * C * Z * X * Y * es, stream) != hipSuccess) return check_launch("sparse_to_bev_nhwc memset");
+  if (N == 0) return BFHIP_OK;
+  BFHIP_REQUIRE(feats && indices && ((uintptr_t)indices % 16) == 0, "sparse_to_bev_nhwc: null/unaligned pointer");
+  dim3 grid(ceil_div((long long)N * C, 256));
+  if (dtype == 1)
+    hipLaunchKernelGGL(sparse_to_bev_nhwc_kernel<unsigned short>, grid, dim3(256), 0, stream, feats, (const int4 *)indices,
+                       N, C, X, Y, Z, (unsigned short *)out);
+  else
+    hipLaunchKernelGGL(sparse_to_bev_nhwc_kernel<float>, grid, dim3(256), 0, stream, feats, (const int4 *)indices, N, C, X,
+                       Y, Z, (float *)out);
+  return check_launch("sparse_to_bev_nhwc");
+}
+
+BFHIP_EXPORT int bfhip_bev_nhwc_to_sparse(const void *grad_out, long long stride_b, long long stride_x,
+                                          long long stride_y, int dtype, const int32_t *indices, int N, int C,
+                                          int Z, float *grad_feats, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BFHIP_REQUIRE(N >= 0 && C > 0 && Z > 0 && (dtype == 0 || dtype == 1) && stride_y >= (long long)C * Z,
+                "bev_nhwc_to_sparse: bad arguments");
+  if (N == 0) return BFHIP_OK;
+  BFHIP_REQUIRE(grad_out && grad_feats && indices && ((uintptr_t)indices % 16) == 0, "bev_nhwc_to_sparse: null/unaligned pointer");
+  dim3 grid(ceil_div((long long)N * C, 256));
+  if (dtype == 1)
+    hipLaunchKernelGGL(bev_nhwc_to_sparse_kernel<unsigned short>, grid, dim3(256), 0, stream, (const unsigned short *)grad_out,
+                       stride_b, stride_x, stride_y, (const int4 *)indices, N, C, Z, grad_feats);
+  else
+    hipLaunchKernelGGL(bev_nhwc_to_sparse_kernel<float>, grid, dim3(256), 0, stream, (const float *)grad_out, stride_b,
+                       stride_x, stride_y, (const int4 *)indices, N, C, Z, grad_feats);
+  return check_launch("bev_nhwc_to_sparse");
 }

@@ -234,6 +234,9 @@ class BaseViewTransform(nn.Module):
         if feat_pm.stride(1) != 1 or feat_pm.stride(0) % 4 or feat_pm.data_ptr() % 16:
             feat_pm = feat_pm.contiguous()
         out = lift_splat(depth_pm.float(), feat_pm.float(), plan)  # [B, nz, nx, ny, C]
+        if out.shape[1] == 1:
+            # nz == 1 (every BEVFusion config): [B, nx, ny, C] IS the channels-last memory of [B, C, nx, ny] -> no copy
+            return out[:, 0].permute(0, 3, 1, 2)
         out = out.permute(0, 4, 1, 2, 3)  # [B, C, nz, nx, ny]
         return torch.cat(out.unbind(dim=2), 1).contiguous()
 
@@ -397,6 +400,23 @@ class DepthLSSTransform(BaseDepthTransform):
             nn.Conv2d(in_channels, self.D + self.C, 1))
         self.downsample = _make_downsample(out_channels, downsample)
 
+    def run_dtransform(self, d):
+        """dtransform with its first layer produced directly in channels-last memory.  Conv2d(1, 8, 1) on the one-channel
+        depth image is a per-pixel outer product with 8 weights; as a conv its output comes back NCHW (a one-channel
+        input carries no layout), which sends the following BatchNorm over [BN, 8, 256, 704] down the slow generic path
+        (1.9 ms forward + 2.4 ms backward per batch of 4 frames)."""
+        conv0 = self.dtransform[0]
+        if not (d.is_cuda and d.dim() == 4 and d.shape[1] == 1 and conv0.kernel_size == (1, 1) and conv0.stride == (1, 1)):
+            return self.dtransform(d)
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else d.dtype
+        BN, _, H, W = d.shape
+        w = conv0.weight.reshape(1, 1, 1, -1).to(dt)
+        b = (conv0.bias if conv0.bias is not None else conv0.weight.new_zeros(w.shape[-1])).to(dt)
+        y = torch.addcmul(b, d.reshape(BN, H, W, 1).to(dt), w).permute(0, 3, 1, 2)  # [BN, 8, H, W], channels-last strides
+        for layer in list(self.dtransform)[1:]:
+            y = layer(y)
+        return y
+
     def gt_depth_distribution(self, d, B, N):
         """Histogram of the sparse depth image over (feature cell, depth bin) (reference :636-686); d [BN,1,iH,iW]."""
         distr, counts = self.depth_distribution(depth=d)
@@ -413,7 +433,7 @@ class DepthLSSTransform(BaseDepthTransform):
         else:
             gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
         with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
-            x = self.depthnet(torch.cat([self.dtransform(d), x], dim=1))
+            x = self.depthnet(torch.cat([self.run_dtransform(d), x], dim=1))
         x = x.float()
         depth = x[:, :self.D].softmax(dim=1)
         est_depth_distr = depth.permute(0, 2, 3, 1).reshape(B, N, fH, fW, self.D)

@@ -95,6 +95,9 @@ class BEVFusionSparseEncoder(nn.Module):
         self.stage_num = len(encoder_channels)
         self.fp16_enabled = False
         self.return_middle_feats = return_middle_feats
+        # False: NCHW-contiguous fp32 output like the reference; True: the same tensor with channels-last strides (in the
+        # autocast dtype when autocast is on) so the NHWC convs of the fuser / BEV backbone take it without a copy
+        self.bev_channels_last = False
         first_order = ("conv",) if order[0] != "conv" else order  # pre-activation variant keeps a bare first conv
         self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
                                                  indice_key="subm1", conv_type="SubMConv3d", order=first_order)
@@ -142,7 +145,11 @@ class BEVFusionSparseEncoder(nn.Module):
             encode_features.append(x)
         out = self.conv_out(encode_features[-1])
         # out.dense() -> [N, C, X, Y, Z] -> permute(0,1,4,2,3) -> view(N, C*Z, X, Y)   (BF/sparse_encoder.py:147-151)
-        spatial_features = out.to_bev()
+        if self.bev_channels_last:
+            dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+            spatial_features = out.to_bev(channels_last=True, dtype=dt if dt == torch.bfloat16 else torch.float32)
+        else:
+            spatial_features = out.to_bev()
         if self.return_middle_feats:
             return spatial_features, encode_features
         return spatial_features

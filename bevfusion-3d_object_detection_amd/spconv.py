@@ -216,6 +216,36 @@ class _ToBevFunction(torch.autograd.Function):
         return g, None, None, None, None, None
 
 
+class _ToBevChannelsLastFunction(torch.autograd.Function):
+    """[N, C] features -> [B, C*Z, X, Y] with channels-last strides (NHWC memory), f32 or bf16; the gradient (a channel
+    slice of a wider channels-last tensor included) is gathered in place."""
+
+    @staticmethod
+    def forward(ctx, features, indices, B, X, Y, Z, dtype):
+        features = features.contiguous().float()
+        N, C = features.shape
+        out = torch.empty((B, X, Y, C * Z), dtype=dtype, device=features.device)
+        _lib.call("bfhip_sparse_to_bev_nhwc", _lib.ptr(features), _lib.ptr(indices), N, C, B, X, Y, Z,
+                  1 if dtype == torch.bfloat16 else 0, _lib.ptr(out), _lib.stream_of(features))
+        ctx.save_for_backward(indices)
+        ctx.shape = (N, C, B, X, Y, Z)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (indices,) = ctx.saved_tensors
+        N, C, B, X, Y, Z = ctx.shape
+        if grad_out.dtype not in (torch.float32, torch.bfloat16):
+            grad_out = grad_out.float()
+        if grad_out.stride(1) != 1:
+            grad_out = grad_out.contiguous(memory_format=torch.channels_last)
+        g = torch.empty((N, C), dtype=torch.float32, device=grad_out.device)
+        _lib.call("bfhip_bev_nhwc_to_sparse", _lib.ptr(grad_out), grad_out.stride(0), grad_out.stride(2), grad_out.stride(3),
+                  1 if grad_out.dtype == torch.bfloat16 else 0, _lib.ptr(indices), N, C, Z, _lib.ptr(g),
+                  _lib.stream_of(grad_out))
+        return g, None, None, None, None, None, None
+
+
 class SparseConvTensor:
     """features f32[N,C], indices i32[N,4] = (batch, x, y, z) in this fork's axis order
     (BF/sparse_encoder.py:133), spatial_shape [X,Y,Z], batch_size."""
@@ -260,9 +290,14 @@ class SparseConvTensor:
         out = bev.view(B, C, Z, X, Y).permute(0, 1, 3, 4, 2)
         return out if channels_first else out.permute(0, 2, 3, 4, 1)
 
-    def to_bev(self):
-        """dense() + permute(0,1,4,2,3) + view(B, C*Z, X, Y) in one kernel (BF/sparse_encoder.py:147-151)."""
+    def to_bev(self, channels_last=False, dtype=None):
+        """dense() + permute(0,1,4,2,3) + view(B, C*Z, X, Y) in one kernel (BF/sparse_encoder.py:147-151).
+        channels_last=True returns the same [B, C*Z, X, Y] tensor with channels-last strides (what the NHWC conv
+        kernels of the BEV backbone consume), optionally already in bf16."""
         X, Y, Z = self.spatial_shape
+        if channels_last:
+            return _ToBevChannelsLastFunction.apply(self.features, self.indices, self.batch_size, X, Y, Z,
+                                                    dtype or torch.float32)
         return _ToBevFunction.apply(self.features, self.indices, self.batch_size, X, Y, Z)
 
 

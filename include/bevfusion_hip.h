@@ -247,6 +247,13 @@ int bfhip_sparse_to_bev(const float *feats, const int32_t *indices, int N, int C
                         int Y, int Z, float *out, void *stream);
 int bfhip_bev_to_sparse(const float *grad_out, const int32_t *indices, int N, int C, int B, int X,
                         int Y, int Z, float *grad_feats, void *stream);
+/* channels-last variants: out (f32 | bf16, dtype 0 | 1) is the NHWC memory of the [B, C*Z, X, Y] map, out[b][x][y][c*Z+z];
+ * the backward reads element (b, ch, x, y) at grad_out[b*stride_b + x*stride_x + y*stride_y + ch] (strides in elements,
+ * channel stride 1), so a channel slice of a wider channels-last gradient is consumed in place. */
+int bfhip_sparse_to_bev_nhwc(const float *feats, const int32_t *indices, int N, int C, int B, int X, int Y, int Z,
+                             int dtype, void *out, void *stream);
+int bfhip_bev_nhwc_to_sparse(const void *grad_out, long long stride_b, long long stride_x, long long stride_y,
+                             int dtype, const int32_t *indices, int N, int C, int Z, float *grad_feats, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * sparse LiDAR depth images + GT depth histogram  (replaces the per-sample torch loop of

@@ -249,3 +249,32 @@ def test_fused_bn1d_matches_torch(dev, C, res, relu):
     # eval mode and unsupported widths fall back to torch's own kernels with identical semantics
     bn.eval(); ref.eval()
     assert torch.allclose(bn(x, relu=relu), torch.relu(ref(x)) if relu else ref(x), rtol=1e-5, atol=1e-5)
+
+
+def test_to_bev_channels_last_matches_nchw(dev):
+    """The channels-last BEV output (f32 and bf16) holds the same values as the NCHW one; its backward reads a channel
+    slice of a wider channels-last gradient in place (what torch.cat's backward hands over in the fuser)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    B, X, Y, Z, C, n = 2, 20, 24, 2, 16, 300
+    cells = rng.choice(B * X * Y * Z, n, replace=False)
+    idx = np.stack(np.unravel_index(cells, (B, X, Y, Z)), 1).astype(np.int32)
+    feats = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(dev)
+    from bevfusion_amd.spconv import SparseConvTensor
+    f0 = feats.clone().requires_grad_(True)
+    f1 = feats.clone().requires_grad_(True)
+    t0 = SparseConvTensor(f0, torch.from_numpy(idx).to(dev), [X, Y, Z], B)
+    t1 = SparseConvTensor(f1, torch.from_numpy(idx).to(dev), [X, Y, Z], B)
+    a = t0.to_bev()
+    b = t1.to_bev(channels_last=True)
+    assert b.shape == a.shape == (B, C * Z, X, Y) and b.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(a, b)
+    h = t1.to_bev(channels_last=True, dtype=torch.bfloat16)
+    assert h.dtype == torch.bfloat16 and torch.equal(h, a.to(torch.bfloat16))
+    wide = torch.randn(B, 8 + C * Z, X, Y, device=dev).contiguous(memory_format=torch.channels_last)
+    a.backward(wide[:, 8:].contiguous())
+    b.backward(wide[:, 8:])          # non-contiguous channel slice, consumed in place
+    assert torch.equal(f0.grad, f1.grad)
+    f1.grad = None
+    h.backward(wide[:, 8:].to(torch.bfloat16))
+    assert torch.allclose(f1.grad, f0.grad, rtol=1e-2, atol=1e-2)
