@@ -19,8 +19,20 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 _WS = {}
 
 
-def _workspace(device, nbytes):
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+_SIZES = {}
+
+
+def _ws_bytes(M, C, dt):
+    """bfhip_bn2d_workspace_bytes, memoised per shape (0 = unsupported shape)."""
+    key = (M, C, dt)
+    n = _SIZES.get(key)
+    if n is None:
+        n = _SIZES[key] = _lib.call_size("bfhip_bn2d_workspace_bytes", M, C, dt)
+    return n
+
+
+def _workspace(device, nbytes, stream):
+    key = (device, stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 22), dtype=torch.uint8, device=device)
@@ -41,11 +53,11 @@ class _BN2dFunction(torch.autograd.Function):
             res = res.contiguous(memory_format=torch.channels_last)
         y = torch.empty_like(x)  # keeps the channels-last strides
         stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
-        nbytes = _lib.call_size("bfhip_bn2d_workspace_bytes", M, C, dt)
-        ws = _workspace(x.device, nbytes)
-        _lib.call("bfhip_bn2d_fwd", _lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), M, C, dt, float(eps),
-                  float(momentum), 1 if relu else 0, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(stats),
-                  _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
+        stream = _lib.stream_of(x)
+        ws = _workspace(x.device, _ws_bytes(M, C, dt), stream)
+        _lib.call("bfhip_bn2d_fwd", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps, momentum,
+                  1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(), y.data_ptr(),
+                  ws.data_ptr(), ws.numel(), stream)
         keep_y = relu and residual is not None  # otherwise the ReLU mask is recomputed from x in the backward
         ctx.save_for_backward(x, y if keep_y else None, stats, weight)
         ctx.relu, ctx.has_res = relu, residual is not None
@@ -63,11 +75,10 @@ class _BN2dFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         dgb = torch.empty(2 * C, dtype=torch.float32, device=x.device)
-        nbytes = _lib.call_size("bfhip_bn2d_workspace_bytes", M, C, dt)
-        ws = _workspace(x.device, nbytes)
-        _lib.call("bfhip_bn2d_bwd", _lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(weight), M, C, dt,
-                  1 if ctx.relu else 0, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgb), _lib.ptr(ws), ws.numel(),
-                  _lib.stream_of(x))
+        stream = _lib.stream_of(x)
+        ws = _workspace(x.device, _ws_bytes(M, C, dt), stream)
+        _lib.call("bfhip_bn2d_bwd", dy.data_ptr(), x.data_ptr(), _lib.ptr(y), stats.data_ptr(), weight.data_ptr(), M, C, dt,
+                  1 if ctx.relu else 0, dx.data_ptr(), _lib.ptr(dres), dgb.data_ptr(), ws.data_ptr(), ws.numel(), stream)
         if dres is not None and ctx.res_dtype != dres.dtype:
             dres = dres.to(ctx.res_dtype)
         return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None
@@ -102,7 +113,7 @@ class BatchNorm2dAct(_LazyBatchCounter, nn.BatchNorm2d):
         return (FUSED_BN2D and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine
                 and self.track_running_stats and self.momentum is not None and x.numel() > x.shape[1]
                 and x.is_contiguous(memory_format=torch.channels_last)
-                and _lib.call_size("bfhip_bn2d_supported", x.numel() // x.shape[1], x.shape[1], _DT[x.dtype]) == 1)
+                and _ws_bytes(x.numel() // x.shape[1], x.shape[1], _DT[x.dtype]) > 0)
 
     def forward(self, x, residual=None, relu=None):
         relu = self.act if relu is None else relu
@@ -128,7 +139,7 @@ class BatchNormRows(_LazyBatchCounter, nn.BatchNorm1d):
     def forward(self, x, relu=False):
         if (FUSED_BN2D and self.training and x.is_cuda and x.dim() == 2 and x.dtype in _DT and self.affine
                 and self.track_running_stats and self.momentum is not None and x.shape[0] > 1 and x.is_contiguous()
-                and _lib.call_size("bfhip_bn2d_supported", x.shape[0], x.shape[1], _DT[x.dtype]) == 1):
+                and _ws_bytes(x.shape[0], x.shape[1], _DT[x.dtype]) > 0):
             self._pending_batches += 1
             M, C = x.shape
             y = _BN2dFunction.apply(x.view(M, C, 1, 1), None, self.weight, self.bias, self.running_mean, self.running_var,
