@@ -122,8 +122,11 @@ class BEVFusion(nn.Module):
                 x = x[0]
         BN, C, H, W = x.size()
         x = x.reshape(B, N, C, H, W)
+        # the view transform's conv stacks run in its own autocast (conv_dtype); when that is on, the bf16 features go in
+        # as they are instead of being widened to fp32 here and narrowed again in front of the first conv
+        keep = getattr(self.view_transform, "conv_dtype", None) is not None and x.dtype == self.view_transform.conv_dtype
         with torch.autocast("cuda", enabled=False):  # fp32 island, as the reference (:177)
-            return self.view_transform(x.float(), points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
+            return self.view_transform(x if keep else x.float(), points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
                                        lidar_aug_matrix, img_metas, geom_feats_precomputed=geom_feats)
 
     def graph_image_trunk(self, sample_imgs, autocast_dtype=None):

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .bn2d import BatchNorm2dAct, BatchNormRows, bn_act
+from .linear_rows import linear_rows
 from .registry import MODELS
 
 
@@ -199,9 +200,9 @@ class PositionEncodingLearned(nn.Module):
         """xyz [B, N, in] -> [B, N, C]."""
         conv1, bn, _, conv2 = self.position_embedding_head
         B, N, _ = xyz.shape
-        h = F.linear(xyz.reshape(B * N, -1), conv1.weight[:, :, 0], conv1.bias)
+        h = linear_rows(xyz.reshape(B * N, -1), conv1.weight[:, :, 0], conv1.bias)
         h = bn(h.contiguous(), relu=True)
-        h = F.linear(h, conv2.weight[:, :, 0], conv2.bias)
+        h = linear_rows(h, conv2.weight[:, :, 0], conv2.bias)
         return h.view(B, N, -1)
 
     def forward(self, xyz):
@@ -210,17 +211,34 @@ class PositionEncodingLearned(nn.Module):
 
 
 class _MHA(nn.Module):
-    """mmcv MultiheadAttention semantics: identity + dropout(attn(q + q_pos, k + k_pos, v)), batch_first."""
+    """mmcv MultiheadAttention semantics: identity + dropout(attn(q + q_pos, k + k_pos, v)), batch_first.
+    Parameters live in an nn.MultiheadAttention (same state-dict keys as the reference's mmcv wrapper: attn.in_proj_weight,
+    attn.out_proj.weight, ...); the computation is spelled out -- three projections, scaled_dot_product_attention (what
+    nn.MultiheadAttention runs when no weights are requested), output projection -- so that the projections of the
+    32 400 BEV keys per sample go through `linear_rows` (split-K weight gradient)."""
 
     def __init__(self, embed_dims, num_heads, dropout=0.0):
         super().__init__()
         self.attn = nn.MultiheadAttention(embed_dims, num_heads, dropout=dropout, batch_first=True)
         self.dropout = nn.Dropout(dropout)
+        self.embed_dims, self.num_heads = embed_dims, num_heads
 
     def forward(self, query, key, value, query_pos=None, key_pos=None):
         q = query if query_pos is None else query + query_pos
         k = key if key_pos is None else key + key_pos
-        return query + self.dropout(self.attn(q, k, value, need_weights=False)[0])
+        E, H = self.embed_dims, self.num_heads
+        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+
+        def proj(t, i):
+            bi = b[i * E:(i + 1) * E] if b is not None else None
+            out = linear_rows(t.reshape(-1, E), w[i * E:(i + 1) * E], bi)
+            return out.view(B, -1, H, E // H).transpose(1, 2)  # [B, H, L, d]
+
+        o = F.scaled_dot_product_attention(proj(q, 0), proj(k, 1), proj(value, 2),
+                                           dropout_p=self.attn.dropout if self.training else 0.0)
+        o = self.attn.out_proj(o.transpose(1, 2).reshape(B, Lq, E))
+        return query + self.dropout(o)
 
 
 @MODELS.register_module()

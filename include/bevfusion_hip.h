@@ -310,6 +310,16 @@ int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, const float *st
                    size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * out f32[M, N] = X^T Y for tall-skinny row-major X [K, M], Y [K, N] (f32 | bf16, dtype 0 | 1), K >> M, N: the weight
+ *   gradient of the linear layers that act on every BEV cell (cross-attention K / V projections and the position
+ *   embedding MLP of the TransFusion decoder layer, BF/transformer.py:10-23,60-105: dW = dY^T X with K = B*180*180).
+ *   K is split over the chip, products and sums in fp32, fixed-order combine (deterministic).
+ * --------------------------------------------------------------------------------------- */
+size_t bfhip_xty_workspace_bytes(long long K, int M, int N);
+int bfhip_xty(const void *X, const void *Y, long long K, int M, int N, int dtype, float *out, void *workspace,
+              size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * TransFusion head: box decoding, target assignment and losses on the device  (SURVEY 8 f-3).
  *   Replaces TransFusionBBoxCoder.decode/encode (BF/utils.py:33-96), HungarianAssigner3D.assign with its three costs
  *   and the `.cpu()` + scipy.optimize.linear_sum_assignment round trip (BF/utils.py:128-151,241-284; IoU as
