@@ -73,6 +73,12 @@ SIGNATURES = {
     "bfhip_bn2d_bwd": (_c_int, [_c_vp] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_xty_workspace_bytes": (_c_sz, [ctypes.c_longlong, _c_int, _c_int]),
     "bfhip_xty": (_c_int, [_c_vp, _c_vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_attn_workspace_bytes": (_c_sz, [_c_int] * 4),
+    "bfhip_attn_fwd": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _c_vp, _c_vp,
+                                                             _c_vp, _c_sz, _c_vp]),
+    "bfhip_attn_bwd": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong] + [_c_vp] * 3 +
+                       [_c_vp, _c_sz, _c_vp]),
+    "bfhip_attn_dropout_mask": (_c_int, [_c_int] * 4 + [ctypes.c_float, ctypes.c_ulonglong, _c_vp, _c_vp]),
     "bfhip_decode_boxes": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp, _c_vp, _c_vp]),
     "bfhip_assign_cost": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 +
                           [_c_vp] * 4),

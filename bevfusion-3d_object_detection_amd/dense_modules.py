@@ -19,6 +19,7 @@ from torch import nn
 
 from .bn2d import BatchNorm2dAct, BatchNormRows, bn_act
 from .linear_rows import linear_rows
+from . import attention as split_attention
 from .registry import MODELS
 
 
@@ -232,13 +233,18 @@ class _MHA(nn.Module):
 
         def proj(t, i):
             bi = b[i * E:(i + 1) * E] if b is not None else None
-            out = linear_rows(t.reshape(-1, E), w[i * E:(i + 1) * E], bi)
-            return out.view(B, -1, H, E // H).transpose(1, 2)  # [B, H, L, d]
+            return linear_rows(t.reshape(-1, E), w[i * E:(i + 1) * E], bi).view(B, -1, E)  # [B, L, H*d]
 
-        o = F.scaled_dot_product_attention(proj(q, 0), proj(k, 1), proj(value, 2),
-                                           dropout_p=self.attn.dropout if self.training else 0.0)
-        o = self.attn.out_proj(o.transpose(1, 2).reshape(B, Lq, E))
-        return query + self.dropout(o)
+        qp, kp, vp = proj(q, 0), proj(k, 1), proj(value, 2)
+        p_drop = self.attn.dropout if self.training else 0.0
+        if split_attention.supported(qp, kp, vp, H):
+            # 200 queries x 32 400 keys: split the key axis over the chip (csrc/attn.hip)
+            o = split_attention.cross_attention(qp, kp, vp, H, p_drop)
+        else:
+            heads = lambda t: t.view(B, -1, H, E // H).transpose(1, 2)  # noqa: E731  [B, H, L, d]
+            o = F.scaled_dot_product_attention(heads(qp), heads(kp), heads(vp), dropout_p=p_drop)
+            o = o.transpose(1, 2).reshape(B, Lq, E)
+        return query + self.dropout(self.attn.out_proj(o))
 
 
 @MODELS.register_module()

@@ -320,6 +320,25 @@ int bfhip_xty(const void *X, const void *Y, long long K, int M, int N, int dtype
               size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Cross attention of few queries over very many keys (the TransFusion decoder layer: 200 queries x 32 400 BEV cells,
+ *   8 heads of 16 channels, dropout on the attention weights; BF/transformer.py:60-105, mmcv MultiheadAttention ->
+ *   torch scaled_dot_product_attention).  Q [B, Lq, H*16], K / V [B, Lk, H*16], O, dO, dQ, dK, dV alike: bf16, row-major;
+ *   head h = channels 16h..16h+15; Lq <= 256.  lse f32[B*H, Lq] (log-sum-exp of the scaled scores) links fwd and bwd.
+ *   The key axis is split over the chip; combines run in a fixed order (bit-reproducible).  dropout_p in [0, 1): keep
+ *   mask = counter hash of (seed, b, h, query, key), regenerated in the backward; bfhip_attn_dropout_mask writes it
+ *   out (u8[B*H, Lq, Lk]) for tests.  The workspace is shared by fwd and bwd.
+ * --------------------------------------------------------------------------------------- */
+size_t bfhip_attn_workspace_bytes(int B, int H, int Lq, int Lk);
+int bfhip_attn_fwd(const void *Q, const void *K, const void *V, int B, int H, int Lq, int Lk, float scale,
+                   float dropout_p, unsigned long long seed, void *O, float *lse, void *workspace,
+                   size_t workspace_bytes, void *stream);
+int bfhip_attn_bwd(const void *Q, const void *K, const void *V, const void *O, const void *dO, const float *lse, int B,
+                   int H, int Lq, int Lk, float scale, float dropout_p, unsigned long long seed, void *dQ, void *dK,
+                   void *dV, void *workspace, size_t workspace_bytes, void *stream);
+int bfhip_attn_dropout_mask(int B, int H, int Lq, int Lk, float dropout_p, unsigned long long seed,
+                            unsigned char *mask, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * TransFusion head: box decoding, target assignment and losses on the device  (SURVEY 8 f-3).
  *   Replaces TransFusionBBoxCoder.decode/encode (BF/utils.py:33-96), HungarianAssigner3D.assign with its three costs
  *   and the `.cpu()` + scipy.optimize.linear_sum_assignment round trip (BF/utils.py:128-151,241-284; IoU as
