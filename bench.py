@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s meas
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
     ap.add_argument("--workload", default="full", choices=["full", "lidar_only", "camera_only", "hotpath_v1", "dist_selftest"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --workload dist_selftest (CPU)")
@@ -183,11 +183,18 @@ class _ModelWorkload:
         self.n_params = sum(p.numel() for p in self.model.parameters())
         self.step_model = self.model
         self._graph_trunk = self.camera and os.environ.get("BENCH_GRAPH_TRUNK", "0") == "1"
+        self.master_weights = self.amp and os.environ.get("BENCH_MASTER_WEIGHTS", "1") == "1"
+        if self.master_weights:
+            # conv / linear weights held in bf16 (what the kernels consume), fp32 masters in the optimizer: same arithmetic
+            # as autocast without ~320 per-step cast launches; DDP then reduces bf16 gradients for these layers
+            from bevfusion_amd.amp import MasterWeightAdamW
+            self.opt = MasterWeightAdamW(self.model, lr=2e-4, weight_decay=0.01, max_grad_norm=35.0)  # before DDP: dtypes fixed
+        else:
+            self.opt = torch.optim.AdamW(self.model.parameters(), lr=2e-4, weight_decay=0.01, fused=True)
         if ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             # BatchNorm statistics stay local (no SyncBN in the reference configs): buffers are not broadcast
             self.step_model = DDP(self.model, device_ids=[local_rank], gradient_as_bucket_view=True, broadcast_buffers=False)
-        self.opt = torch.optim.AdamW(self.model.parameters(), lr=2e-4, weight_decay=0.01, fused=True)
         self.parse_losses = BEVFusion.parse_losses
         self._params = [p for p in self.model.parameters() if p.requires_grad]
         # ground truth as a dataloader hands it over: per-frame host tensors (boxes [G, 9], labels [G]), G ~ U(15, 60)
@@ -213,13 +220,14 @@ class _ModelWorkload:
             self.model.graph_image_trunk(self.inputs["imgs"], torch.bfloat16 if self.amp else None)
 
     def step(self):
-        self.opt.zero_grad(set_to_none=True)
+        self.opt.zero_grad() if self.master_weights else self.opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
             # BEVFusion.loss: extract_feat + TransFusion head + Hungarian targets + focal / L1 / gaussian-focal losses
             losses = self.step_model(self.inputs, None, self.gts)
             loss = self.parse_losses(losses)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self._params, 35.0, foreach=True)
+        if not self.master_weights:
+            torch.nn.utils.clip_grad_norm_(self._params, 35.0, foreach=True)
         self.opt.step()
         return loss
 

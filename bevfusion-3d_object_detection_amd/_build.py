@@ -68,7 +68,37 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         if verbose:
             print("[build] linked", LIB, file=sys.stderr)
+    build_torch_binding(force=force, verbose=verbose)
     return LIB
+
+
+TORCH_EXT = os.path.join(CSRC, "bfhip_torch_ext.so")
+
+
+def build_torch_binding(force=False, verbose=True):
+    """csrc/torch_binding.cpp -> csrc/bfhip_torch_ext.so: host-only C++ autograd front-ends (pybind11 module) over the C
+    ABI, compiled with g++ against the installed torch.  Optional: the Python (ctypes) path is used when it is absent."""
+    import sysconfig
+    import torch
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    hdr = os.path.join(HERE, "..", "include", "bevfusion_hip.h")
+    if not (force or _stale(TORCH_EXT, [src, hdr, LIB])):
+        return TORCH_EXT
+    tdir = os.path.dirname(torch.__file__)
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", TORCH_EXT,
+           "-I" + os.path.join(tdir, "include"), "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+           "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=bfhip_torch_ext",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-L" + os.path.join(tdir, "lib"), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python",
+           "-L" + CSRC, "-lbevfusion_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tdir, "lib"), "-Wno-attributes"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch binding failed to build:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("[build] built", TORCH_EXT, file=sys.stderr)
+    return TORCH_EXT
 
 
 if __name__ == "__main__":

@@ -111,6 +111,31 @@ def load():
     return _lib
 
 
+_torch_ext = False
+
+
+def torch_ext():
+    """csrc/bfhip_torch_ext.so (C++ autograd front-ends, csrc/torch_binding.cpp) or None when it has not been built or
+    BFHIP_TORCH_EXT=0.  Same kernels either way: it only replaces the ctypes + Python autograd plumbing."""
+    global _torch_ext
+    if _torch_ext is False:
+        _torch_ext = None
+        path = os.path.join(_HERE, "csrc", "bfhip_torch_ext.so")
+        if os.environ.get("BFHIP_TORCH_EXT", "1") == "1" and os.path.exists(path):
+            import importlib.util
+            load()
+            try:
+                spec = importlib.util.spec_from_file_location("bfhip_torch_ext", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if mod.abi_version() == load().bfhip_abi_version():
+                    _torch_ext = mod
+            except (ImportError, OSError) as e:  # binding built against another torch: keep the ctypes path
+                import warnings
+                warnings.warn("bfhip_torch_ext not usable (%s); using the ctypes binding" % e)
+    return _torch_ext
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().bfhip_last_error().decode("utf-8", "replace")

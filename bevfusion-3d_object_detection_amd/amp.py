@@ -1,0 +1,57 @@
+"""bf16 parameters with fp32 master weights for the dense (MFMA) layers.
+
+Under plain autocast every conv / linear weight is re-cast fp32 -> bf16 in each forward and its bf16 gradient is cast
+back to fp32 in each backward: ~320 tiny launches per step for this model.  Here the weights of those layers ARE bf16
+(what the kernels consume), the optimizer owns fp32 master copies, and the two conversions are one multi-tensor copy
+each per step.  The arithmetic is unchanged: the forward uses the same bf16 values autocast would produce and the weight
+gradient the same bf16 tensor the bf16 kernels emit.  With DDP the gradient all-reduce of these layers moves half the
+bytes (bf16 buckets).  Layers that the model runs in fp32 islands, BatchNorm / LayerNorm and the sparse encoder keep
+fp32 parameters."""
+import torch
+from torch import nn
+
+_LOW_TYPES = (nn.Conv1d, nn.Conv2d, nn.ConvTranspose2d, nn.Linear, nn.MultiheadAttention)
+
+
+def low_precision_parameters(model, exclude=("pts_middle_encoder", "heatmap_head")):
+    """Parameters of the conv / linear / attention-projection layers that run under bf16 autocast."""
+    out, seen = [], set()
+    for name, mod in model.named_modules():
+        if any(part in name.split(".") for part in exclude) or not isinstance(mod, _LOW_TYPES):
+            continue
+        for p in mod.parameters(recurse=False):
+            if p.requires_grad and p.dtype == torch.float32 and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+class MasterWeightAdamW:
+    """AdamW (fused) over fp32 master copies of `low` (converted to bf16 in place) plus the remaining fp32 parameters."""
+
+    def __init__(self, model, lr, weight_decay, max_grad_norm=None, exclude=("pts_middle_encoder", "heatmap_head")):
+        self.low = low_precision_parameters(model, exclude)
+        low_ids = {id(p) for p in self.low}
+        self.other = [p for p in model.parameters() if p.requires_grad and id(p) not in low_ids]
+        self.master = [p.detach().clone().float() for p in self.low]
+        for p in self.low:
+            p.data = p.data.to(torch.bfloat16)
+        for m in self.master:
+            m.grad = torch.zeros_like(m)
+        self.max_grad_norm = max_grad_norm
+        self.opt = torch.optim.AdamW(self.master + self.other, lr=lr, weight_decay=weight_decay, fused=True)
+
+    def zero_grad(self):
+        for p in self.low:
+            p.grad = None
+        for p in self.other:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        grads = [p.grad for p in self.low]
+        torch._foreach_copy_([m.grad for m in self.master], grads)  # bf16 -> fp32, one multi-tensor kernel
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.master + self.other, self.max_grad_norm, foreach=True)
+        self.opt.step()
+        torch._foreach_copy_(self.low, self.master)                  # fp32 -> bf16

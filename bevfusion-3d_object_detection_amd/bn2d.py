@@ -19,6 +19,13 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 _WS = {}
 
 
+def _apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu):
+    ext = _lib.torch_ext()
+    if ext is not None:  # C++ autograd front-end: same kernels, ~3x less host time per call
+        return ext.bn2d(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu)
+    return _BN2dFunction.apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu)
+
+
 _SIZES = {}
 
 
@@ -119,8 +126,8 @@ class BatchNorm2dAct(_LazyBatchCounter, nn.BatchNorm2d):
         relu = self.act if relu is None else relu
         if self.fusable(x):
             self._pending_batches += 1
-            return _BN2dFunction.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                                       self.momentum, relu)
+            return _apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
+                          relu)
         self._flush_batches()
         out = super().forward(x)
         if residual is not None:
@@ -142,8 +149,8 @@ class BatchNormRows(_LazyBatchCounter, nn.BatchNorm1d):
                 and _ws_bytes(x.shape[0], x.shape[1], _DT[x.dtype]) > 0):
             self._pending_batches += 1
             M, C = x.shape
-            y = _BN2dFunction.apply(x.view(M, C, 1, 1), None, self.weight, self.bias, self.running_mean, self.running_var,
-                                    self.eps, self.momentum, relu)
+            y = _apply(x.view(M, C, 1, 1), None, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                       self.momentum, relu)
             return y.view(M, C)
         self._flush_batches()
         out = super().forward(x)

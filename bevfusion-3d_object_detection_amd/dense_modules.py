@@ -118,7 +118,12 @@ class GeneralizedLSSFPN(nn.Module):
         laterals = [inputs[i + self.start_level] for i in range(len(inputs))]
         used = len(laterals) - 1
         for i in range(used - 1, -1, -1):
-            x = F.interpolate(laterals[i + 1], size=laterals[i].shape[2:], **self.upsample_cfg)
+            # autocast would widen the bilinear upsampling (and with it the concat and the cast in front of the 1x1 conv) to
+            # fp32; the bf16 kernel interpolates with fp32 arithmetic and rounds once, within the bf16 tolerance of the path
+            with torch.autocast("cuda", enabled=False):
+                x = F.interpolate(laterals[i + 1], size=laterals[i].shape[2:], **self.upsample_cfg)
+            if x.dtype != laterals[i].dtype:
+                x = x.to(laterals[i].dtype)
             laterals[i] = self.fpn_convs[i](self.lateral_convs[i](torch.cat([laterals[i], x], dim=1)))
         return tuple(laterals[i] for i in range(used))
 

@@ -356,6 +356,10 @@ class BatchNorm1dAct(nn.BatchNorm1d):
         if fused:
             if self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)
+            ext = _lib.torch_ext()
+            if ext is not None:
+                return ext.bn1d(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                self.momentum, relu)
             return _BN1dFunction.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                        self.momentum, relu)
         out = super().forward(x)
