@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
 from .bn2d import BatchNorm2dAct, BatchNormRows, bn_act
 from .linear_rows import linear_rows
 from . import attention as split_attention
@@ -82,6 +83,39 @@ class ResNet50(nn.Module):
         return tuple(outs)
 
 
+class _Upsample2x(torch.autograd.Function):
+    """Exact-2x bilinear upsampling of a channels-last map (csrc/upsample.hip); the backward is a gather."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.call("bfhip_upsample2x_nhwc", x.data_ptr(), out.data_ptr(), B, H, W, C, 1 if x.dtype == torch.bfloat16 else 0, 0,
+                  _lib.stream_of(x))
+        ctx.dims = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.dims
+        g = g.contiguous(memory_format=torch.channels_last)
+        gin = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+        _lib.call("bfhip_upsample2x_nhwc", g.data_ptr(), gin.data_ptr(), B, H, W, C, 1 if g.dtype == torch.bfloat16 else 0, 1,
+                  _lib.stream_of(g))
+        return gin
+
+
+def upsample_to(x, size, cfg):
+    """F.interpolate(x, size=size, **cfg); the exact-2x bilinear case on a channels-last GPU map runs in the input dtype
+    with the gather backward (autocast would widen it to fp32, and the library backward uses atomics)."""
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if (x.is_cuda and x.dim() == 4 and cfg.get("mode") == "bilinear" and not cfg.get("align_corners", False)
+            and tuple(size) == (2 * x.shape[2], 2 * x.shape[3]) and x.dtype in (torch.float32, torch.bfloat16)
+            and x.shape[1] % vec == 0 and x.is_contiguous(memory_format=torch.channels_last)):
+        return _Upsample2x.apply(x)
+    return F.interpolate(x, size=size, **cfg)
+
+
 def _conv_module(cin, cout, k, padding=0, norm=True, act=True, eps=1e-5, momentum=0.1, stride=1):
     layers = [nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=not norm)]
     if norm and act:
@@ -118,10 +152,7 @@ class GeneralizedLSSFPN(nn.Module):
         laterals = [inputs[i + self.start_level] for i in range(len(inputs))]
         used = len(laterals) - 1
         for i in range(used - 1, -1, -1):
-            # autocast would widen the bilinear upsampling (and with it the concat and the cast in front of the 1x1 conv) to
-            # fp32; the bf16 kernel interpolates with fp32 arithmetic and rounds once, within the bf16 tolerance of the path
-            with torch.autocast("cuda", enabled=False):
-                x = F.interpolate(laterals[i + 1], size=laterals[i].shape[2:], **self.upsample_cfg)
+            x = upsample_to(laterals[i + 1], laterals[i].shape[2:], self.upsample_cfg)
             if x.dtype != laterals[i].dtype:
                 x = x.to(laterals[i].dtype)
             laterals[i] = self.fpn_convs[i](self.lateral_convs[i](torch.cat([laterals[i], x], dim=1)))

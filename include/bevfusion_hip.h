@@ -339,6 +339,13 @@ int bfhip_attn_dropout_mask(int B, int H, int Lq, int Lk, float dropout_p, unsig
                             unsigned char *mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Bilinear 2x upsampling of channels-last maps [B, H, W, C] -> [B, 2H, 2W, C] (f32 | bf16), torch's align_corners=False
+ *   index rule; the LSS-FPN's top-down path (BF/bevfusion_necks.py:76-88).  dir 0 = forward; dir 1 = backward as a gather
+ *   (src = grad of the output, dst = grad of the input): no atomics, deterministic.  C % (4 | 8) == 0.
+ * --------------------------------------------------------------------------------------- */
+int bfhip_upsample2x_nhwc(const void *src, void *dst, int B, int H, int W, int C, int dtype, int dir, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * TransFusion head: box decoding, target assignment and losses on the device  (SURVEY 8 f-3).
  *   Replaces TransFusionBBoxCoder.decode/encode (BF/utils.py:33-96), HungarianAssigner3D.assign with its three costs
  *   and the `.cpu()` + scipy.optimize.linear_sum_assignment round trip (BF/utils.py:128-151,241-284; IoU as

@@ -122,3 +122,24 @@ def test_position_encoding_rows_equals_conv1d_stack(dev):
             continue
         assert rel(p.grad, q.grad) < 1e-3, n
     assert rel(pe.position_embedding_head[1].running_var, ref[1].running_var) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("shape", [(3, 64, 8, 22), (2, 256, 16, 44), (1, 8, 1, 1), (2, 16, 5, 3)])
+def test_upsample2x_matches_interpolate(dev, dtype, tol, shape):
+    from bevfusion_amd.dense_modules import upsample_to
+    torch.manual_seed(0)
+    x = torch.randn(shape, device=dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    cfg = dict(mode="bilinear", align_corners=False)
+    size = (2 * shape[2], 2 * shape[3])
+    y = upsample_to(x, size, cfg)
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.interpolate(xr, size=size, **cfg)
+    assert y.dtype == dtype and y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel(y.float(), yr) < tol
+    g = torch.randn_like(yr)
+    y.backward(g.to(dtype))
+    yr.backward(g.to(dtype).float())
+    assert rel(x.grad.float(), xr.grad) < tol
+    # non-2x sizes take the torch path
+    assert upsample_to(x.detach(), (size[0] + 1, size[1]), cfg).shape[2] == size[0] + 1
