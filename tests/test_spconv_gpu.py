@@ -61,7 +61,7 @@ def test_sparse_rulebook_bit_exact(dev, shape, ksize, stride, padding):
     assert int(data.n_pairs.sum().item()) == (pf >= 0).sum()
 
 
-@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 64), (64, 64), (128, 128), (7, 9)])
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (32, 32), (16, 32), (32, 64), (64, 64), (128, 128), (7, 9)])
 def test_conv_fwd_bwd_vs_oracle(dev, cin, cout):
     B, shape, n = 2, (40, 36, 9), 6000
     idx, feats = random_sparse(B, shape, n, cin, seed=cin + cout)
