@@ -157,26 +157,28 @@ class BEVFusion(nn.Module):
         points = batch_inputs_dict.get("points", None)
         features = []
         depth_loss = 0.0
-        # LiDAR branch first: its host reads (voxel counts, one N_out per strided sparse conv) then happen while the
-        # stream is nearly empty, and the long camera branch is queued behind them with no further sync
-        # (the reference runs camera first, BF/bevfusion.py:305-361; the fused feature order [img, pts] is unchanged)
+        # Two orders.  Single stream: LiDAR branch first -- its host reads (voxel counts, one N_out per strided sparse conv)
+        # happen while the stream is nearly empty and the long camera branch is queued behind them with no further sync
+        # (the reference runs camera first, BF/bevfusion.py:305-361; the fused feature order [img, pts] is unchanged).
+        # Two streams (lidar_side_stream): camera branch FIRST on the main stream, then the LiDAR branch on a side stream that
+        # only depends on the state of the main stream at entry.  Its host reads wait for the side stream alone, its small
+        # kernels overlap the camera forward, and -- because the autograd engine runs the most recently recorded nodes
+        # first -- its backward is launched right after the fuser's and overlaps the long camera backward instead of
+        # trailing it.
         pts_feature = None
         side = None
-        if self.pts_middle_encoder is not None and points is not None:
-            overlap = (self.lidar_side_stream and imgs is not None and self.view_transform is not None
-                       and points[0].is_cuda)
-            if overlap:
-                # the sparse LiDAR kernels are small for the chip (a few hundred workgroups); on their own HIP stream
-                # they (and, through autograd, their backward) overlap the dense camera branch on the main stream
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(device=points[0].device)
-                side, main = self._side_stream, torch.cuda.current_stream(points[0].device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    pts_feature = self.extract_pts_feat(batch_inputs_dict)
-            else:
-                pts_feature = self.extract_pts_feat(batch_inputs_dict)
-        if imgs is not None and self.view_transform is not None:
+        has_cam = imgs is not None and self.view_transform is not None
+        has_pts = self.pts_middle_encoder is not None and points is not None
+        overlap = bool(has_pts and has_cam and self.lidar_side_stream and points[0].is_cuda)
+        if overlap:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=points[0].device)
+            side, main = self._side_stream, torch.cuda.current_stream(points[0].device)
+            entry = torch.cuda.Event()
+            entry.record(main)
+        elif has_pts:
+            pts_feature = self.extract_pts_feat(batch_inputs_dict)
+        if has_cam:
             mats = {}
             for key, meta_key in (("lidar2img", "lidar2img"), ("cam2img", "cam2img"), ("cam2lidar", "cam2lidar"),
                                   ("img_aug_matrix", "img_aug_matrix"), ("lidar_aug_matrix", "lidar_aug_matrix")):
@@ -191,6 +193,12 @@ class BEVFusion(nn.Module):
                                                             mats["lidar_aug_matrix"], batch_input_metas,
                                                             geom_feats=batch_inputs_dict.get("geom_feats"))
             features.append(img_feature)
+        if overlap:
+            # the sparse LiDAR kernels are small for the chip (a few hundred workgroups); on their own HIP stream they
+            # (and, through autograd, their backward) overlap the dense camera branch on the main stream
+            side.wait_event(entry)
+            with torch.cuda.stream(side):
+                pts_feature = self.extract_pts_feat(batch_inputs_dict)
         if pts_feature is not None:
             if side is not None:
                 main = torch.cuda.current_stream(pts_feature.device)
