@@ -418,16 +418,20 @@ def main():
         if not cpu_mode:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        wl.step()
+    first_loss = None
+    for i in range(args.warmup):
+        r = wl.step()
+        if i == 0 and torch.is_tensor(r):
+            first_loss = r.detach()
     barrier()
     if not cpu_mode:
         _lib.profile_enable(True)
         for op in _lib.OPS:
             _lib.profile_read(op, reset=True)
     t0 = time.perf_counter()
+    last_loss = None
     for _ in range(args.steps):
-        wl.step()
+        last_loss = wl.step()
     barrier()
     dt = time.perf_counter() - t0
     prof = {}
@@ -485,6 +489,10 @@ def main():
         }
         if hasattr(wl, "n_params"):
             line["config"]["trainable_params"] = wl.n_params
+        if torch.is_tensor(first_loss) and torch.is_tensor(last_loss):
+            # the optimizer really steps: total loss of the (fixed) batch at the first warm-up step and at the last timed step
+            line["config"]["loss_first_step"] = round(float(first_loss), 4)
+            line["config"]["loss_last_step"] = round(float(last_loss.detach()), 4)
         if cpu_mode:
             line["data"] = "synthetic (CPU plumbing rehearsal, not a performance number)"
             line["config"]["grad_fingerprint"] = wl.grad_fingerprint()

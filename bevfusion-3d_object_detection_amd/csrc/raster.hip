@@ -95,15 +95,19 @@ __global__ __launch_bounds__(256) void hist_from_depth_kernel(const float *__res
   }
 }
 
+// one wave per (camera, feature cell): lanes stride over the D bins (coalesced); counts are small integers, so the
+// order of the sum does not matter (exact in fp32)
 __global__ __launch_bounds__(256) void hist_normalise_kernel(const float *__restrict__ counts, long long ncell,
                                                              int D, float *__restrict__ distr) {
-  long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long cell = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (cell >= ncell) return;
   const float *c = counts + cell * D;
   float s = 0.f;
-  for (int b = 0; b < D; ++b) s += c[b];
-  float den = s + 1e-8f;
-  for (int b = 0; b < D; ++b) distr[cell * D + b] = c[b] / den;
+  for (int b = lane; b < D; b += 64) s += c[b];
+  for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+  const float den = s + 1e-8f;
+  for (int b = lane; b < D; b += 64) distr[cell * D + b] = c[b] / den;
 }
 
 }  // namespace
@@ -165,6 +169,6 @@ BFHIP_EXPORT int bfhip_depth_histogram(const float *depth, int BN, int iH, int i
     hipLaunchKernelGGL(hist_from_depth_kernel, dim3(ceil_div(npix, 256)), dim3(256), 0, stream, depth, npix, iH, iW, fH, fW, D,
                        lo, cmax, half, step, counts);
   }
-  hipLaunchKernelGGL(hist_normalise_kernel, dim3(ceil_div(ncell, 256)), dim3(256), 0, stream, counts, ncell, D, distr);
+  hipLaunchKernelGGL(hist_normalise_kernel, dim3(ceil_div(ncell * 64, 256)), dim3(256), 0, stream, counts, ncell, D, distr);
   return check_launch("depth_histogram");
 }

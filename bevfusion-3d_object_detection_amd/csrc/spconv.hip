@@ -293,73 +293,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
 }
 
 // -------------------------------------------------------------------------------- forward / dgrad
-// one wave: R row tiles of 16 rows x NT column tiles of 16; Kdim = CC*16 channels per offset.
-template <int NT, int R>
-__global__ __launch_bounds__(256) void spconv_gemm_kernel(const float *__restrict__ in, int Kdim,
-                                                          const f32x4 *__restrict__ Wp,
-                                                          const int *__restrict__ pairs, int ld,
-                                                          int KV, int n_rows, int Ndim,
-                                                          float *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long row_base = wave * (R * 16);
-  if (row_base >= n_rows) return;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int CC = Kdim >> 4;
-  f32x4 acc[R][NT];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  for (int k = 0; k < KV; ++k) {
-    int idx[R];
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      long long row = row_base + r * 16 + lr;
-      idx[r] = row < n_rows ? pairs[(size_t)k * ld + row] : -1;
-      any |= idx[r] >= 0;
-    }
-    if (!__any(any)) continue;  // wave-uniform: no row of this tile uses offset k
-    for (int cc = 0; cc < CC; ++cc) {
-      f32x4 a[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        a[r] = idx[r] >= 0 ? *(const f32x4 *)(in + (size_t)idx[r] * Kdim + cc * 16 + lq * 4)
-                           : (f32x4){0.f, 0.f, 0.f, 0.f};
-      f32x4 b[NT];
-      const f32x4 *wp = Wp + ((size_t)(k * CC + cc) * NT) * 64 + lane;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = wp[nt * 64];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[nt][j], acc[r][nt], 0, 0, 0);
-    }
-  }
-  // C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      long long row = row_base + r * 16 + lq * 4 + i;
-      if (row < n_rows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          int col = nt * 16 + lr;
-          if (col < Ndim) out[(size_t)row * Ndim + col] = acc[r][nt][i];
-        }
-      }
-    }
-}
-
 // Workgroup version: 4 waves share every weight tile through LDS (double buffered, one barrier per
 // (offset, 16-channel chunk) step); the workgroup skips offsets none of its 4*R*16 rows uses.
-// Weight traffic from L2 drops 4x versus the per-wave kernel above; A rows are still gathered per wave.
+// Weight traffic from L2 drops 4x versus one weight fetch per wave; A rows are still gathered per wave.
 template <int NT, int R>
 __global__ __launch_bounds__(256) void spconv_gemm_lds_kernel(const float *__restrict__ in, int Kdim,
                                                               const f32x4 *__restrict__ Wp,
