@@ -20,7 +20,7 @@ FLAGS = [
     "-ffp-contract=off",                       # index math must match the reference's unfused fp32
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
-]
+] + os.environ.get("BFHIP_EXTRA_FLAGS", "").split()
 
 
 def hipcc():

@@ -45,9 +45,9 @@ SIGNATURES = {
     "bfhip_rulebook_sort_rows_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "bfhip_rulebook_sort_rows": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_spconv_gemm": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
-    "bfhip_spconv_gemm_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_spconv_gemm_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_sz, _c_vp]),
     "bfhip_spconv_wgrad_workspace_bytes": (_c_sz, [_c_int] * 4),
-    "bfhip_spconv_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_spconv_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp, _c_vp, _c_int, _c_vp, _c_sz, _c_vp]),
     "bfhip_sparse_to_bev": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "bfhip_bev_to_sparse": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp, _c_vp]),
     "bfhip_dynamic_scatter_workspace_bytes": (_c_sz, [_c_int]),

@@ -467,14 +467,20 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__r
   Wp[t] = (__bf16)v;
 }
 
-template <int NT, int R>
-__global__ __launch_bounds__(256) void spconv_gemm_bf16_kernel(const float *__restrict__ in, int Kdim,
+template <int NT, int R, bool IO16>
+__global__ __launch_bounds__(256) void spconv_gemm_bf16_kernel(const void *__restrict__ in_, int Kdim,
                                                                const bf16x8 *__restrict__ Wp,
                                                                const int *__restrict__ pairs, int ld,
                                                                int KV, int n_rows, int Ndim,
                                                                const int *__restrict__ perm,
                                                                const unsigned *__restrict__ row_mask,
-                                                               float *__restrict__ out) {
+                                                               void *__restrict__ out_) {
+  // IO16: features stored in bf16 (gathered rows are the MFMA operand as they are: one 16-byte load per lane and step,
+  // half the gather traffic of fp32 storage) and the output rounded to bf16 once; otherwise fp32 in / fp32 out.
+  const float *in = (const float *)in_;
+  const __bf16 *in16 = (const __bf16 *)in_;
+  float *out = (float *)out_;
+  __bf16 *out16 = (__bf16 *)out_;
   __shared__ bf16x8 sB[2][NT * 64];
   __shared__ unsigned s_mask;
   const int tid = threadIdx.x;
@@ -548,9 +554,14 @@ __global__ __launch_bounds__(256) void spconv_gemm_bf16_kernel(const float *__re
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (ix[r] >= 0 && ch < Kdim) {
-        const float *src = in + (size_t)ix[r] * Kdim + ch;
-        lo[r] = *(const f32x4 *)src;
-        hi[r] = *(const f32x4 *)(src + 4);
+        if (IO16) {
+          lo[r] = *(const f32x4 *)(in16 + (size_t)ix[r] * Kdim + ch);  // 8 bf16 carried in one 16-byte register group
+          hi[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+          const float *src = in + (size_t)ix[r] * Kdim + ch;
+          lo[r] = *(const f32x4 *)src;
+          hi[r] = *(const f32x4 *)(src + 4);
+        }
       } else {
         lo[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
         hi[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -580,8 +591,12 @@ __global__ __launch_bounds__(256) void spconv_gemm_bf16_kernel(const float *__re
       bf16x8 a[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        a[r][0] = (__bf16)alo[r][0]; a[r][1] = (__bf16)alo[r][1]; a[r][2] = (__bf16)alo[r][2]; a[r][3] = (__bf16)alo[r][3];
-        a[r][4] = (__bf16)ahi[r][0]; a[r][5] = (__bf16)ahi[r][1]; a[r][6] = (__bf16)ahi[r][2]; a[r][7] = (__bf16)ahi[r][3];
+        if (IO16) {
+          a[r] = __builtin_bit_cast(bf16x8, alo[r]);
+        } else {
+          a[r][0] = (__bf16)alo[r][0]; a[r][1] = (__bf16)alo[r][1]; a[r][2] = (__bf16)alo[r][2]; a[r][3] = (__bf16)alo[r][3];
+          a[r][4] = (__bf16)ahi[r][0]; a[r][5] = (__bf16)ahi[r][1]; a[r][6] = (__bf16)ahi[r][2]; a[r][7] = (__bf16)ahi[r][3];
+        }
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -611,7 +626,10 @@ __global__ __launch_bounds__(256) void spconv_gemm_bf16_kernel(const float *__re
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           int col = nt * 16 + lr;
-          if (col < Ndim) out[(size_t)row * Ndim + col] = acc[r][nt][i];
+          if (col < Ndim) {
+            if (IO16) out16[(size_t)row * Ndim + col] = (__bf16)acc[r][nt][i];
+            else out[(size_t)row * Ndim + col] = acc[r][nt][i];
+          }
         }
       }
     }
@@ -722,12 +740,36 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float *__restri
     }
 }
 
+// 4 consecutive channels of a feature row as fp32; features are f32 or (IO16) bf16.  Split in two steps so that a group of
+// gathers can be issued back to back and converted afterwards: with the conversion next to the load (inside the
+// predicated block) the compiler waits for each gather before issuing the next -- 8 serialised L2 round trips per K group,
+// measured 1.8x slower than the fp32 kernel.  Invalid lanes load row 0 (always mapped) and are zeroed by a select.
+template <bool IO16>
+__device__ __forceinline__ uint4 ldrow_raw(const void *base, size_t off) {
+  if (IO16) return *(const uint4 *)((const unsigned short *)base + (off & ~(size_t)7));  // aligned 8-channel group
+  return *(const uint4 *)((const float *)base + off);
+}
+template <bool IO16>
+__device__ __forceinline__ f32x4 ldrow_cvt(uint4 q, size_t off, bool ok) {
+  f32x4 r;
+  if (IO16) {
+    const bool hi = (off & 4) != 0;
+    const unsigned a = hi ? q.z : q.x, b = hi ? q.w : q.y;
+    r = (f32x4){__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16),
+                __uint_as_float(b & 0xffff0000u)};
+  } else {
+    r = (f32x4){__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+  }
+  return ok ? r : (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
 // v2: one wave = (offset k, row split s, 64-ci block, 64-co block).  Per K-step of 4 rows every lane
 // loads ONE float4 of in (row n0+q, channels 4a..4a+3) and ONE float4 of dout; the 16 MFMAs (c,d) then use
 // element c of the first and element d of the second:  D_cd[a][a'] += in[row][4a+c] * dout[row][4a'+d],
 // i.e. a 64x64 block of dW with channel index 4*lane_id + component.  2 coalesced 16-B loads per 16 MFMAs.
-__global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__restrict__ in, int Cin,
-                                                             const float *__restrict__ dout, int Cout,
+template <bool IO16>
+__global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const void *__restrict__ in, int Cin,
+                                                             const void *__restrict__ dout, int Cout,
                                                              const int *__restrict__ pairs, int ld,
                                                              int KV, int n_rows, int S, int GI, int GJ,
                                                              const int *__restrict__ perm,
@@ -755,7 +797,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__rest
   // of ~50 % holes at the dense stages (and ~85 % at stage 1).
   __shared__ int2 s_list[4][64];
   int2 *list = s_list[threadIdx.x >> 6];
-  constexpr int U = 4;
+  constexpr int U = 4;  // 16 pairs = 8 gathers in flight per group (U = 8 measured no faster: MFMA issue and gather latency add up at ~2 waves per SIMD)
   for (int chunk = r0; chunk < r1; chunk += 64) {
     const int row = chunk + lane;
     const int pr = row < r1 ? pairs[(size_t)k * ld + (perm ? perm[row] : row)] : -1;
@@ -773,11 +815,19 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__rest
         e[u] = j < cnt ? list[j] : make_int2(-1, -1);
       }
       f32x4 av[U], bv[U];
+      uint4 ra[U], rb[U];
+      size_t oa[U], ob[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // all gathers of the group in flight together
+        oa[u] = (e[u].x >= 0 && ci_ok) ? (size_t)e[u].x * Cin + ci : 0;
+        ob[u] = (e[u].x >= 0 && co_ok) ? (size_t)e[u].y * Cout + co : 0;
+        ra[u] = ldrow_raw<IO16>(in, oa[u]);
+        rb[u] = ldrow_raw<IO16>(dout, ob[u]);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool ok = e[u].x >= 0;
-        av[u] = (ok && ci_ok) ? *(const f32x4 *)(in + (size_t)e[u].x * Cin + ci) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        bv[u] = (ok && co_ok) ? *(const f32x4 *)(dout + (size_t)e[u].y * Cout + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        av[u] = ldrow_cvt<IO16>(ra[u], oa[u], e[u].x >= 0 && ci_ok);
+        bv[u] = ldrow_cvt<IO16>(rb[u], ob[u], e[u].x >= 0 && co_ok);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -814,9 +864,9 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const float *__rest
 // channels 4a..4a+3 of pair (lq, r), so one K step consumes 4R pairs and the block's R diagonal C x C sub-blocks each
 // accumulate their own pairs (the off-diagonal ones mix different pairs and are dropped).  R times fewer MFMAs and
 // loads per pair; the R diagonal blocks are summed with cross-lane shuffles in the epilogue.
-template <int R>
-__global__ __launch_bounds__(256) void spconv_wgrad_packed_kernel(const float *__restrict__ in,
-                                                                  const float *__restrict__ dout,
+template <int R, bool IO16>
+__global__ __launch_bounds__(256) void spconv_wgrad_packed_kernel(const void *__restrict__ in,
+                                                                  const void *__restrict__ dout,
                                                                   const int *__restrict__ pairs, int ld, int KV,
                                                                   int n_rows, int S, float *__restrict__ partial) {
   constexpr int C = 64 / R, AV = 16 / R;  // channels, channel vectors per row group
@@ -847,13 +897,23 @@ __global__ __launch_bounds__(256) void spconv_wgrad_packed_kernel(const float *_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     f32x4 av[U], bv[U];
+    uint4 ra[U], rb[U];
+    size_t oa[U], ob[U];
+    bool okv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {  // all gathers of the chunk in flight together
       const int j = 4 * R * u + lq * R + r;
       const int2 e = j < cnt ? list[j] : make_int2(-1, -1);
-      const bool ok = e.x >= 0;
-      av[u] = ok ? *(const f32x4 *)(in + (size_t)e.x * C + a * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      bv[u] = ok ? *(const f32x4 *)(dout + (size_t)e.y * C + a * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      okv[u] = e.x >= 0;
+      oa[u] = okv[u] ? (size_t)e.x * C + a * 4 : 0;
+      ob[u] = okv[u] ? (size_t)e.y * C + a * 4 : 0;
+      ra[u] = ldrow_raw<IO16>(in, oa[u]);
+      rb[u] = ldrow_raw<IO16>(dout, ob[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      av[u] = ldrow_cvt<IO16>(ra[u], oa[u], okv[u]);
+      bv[u] = ldrow_cvt<IO16>(rb[u], ob[u], okv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1016,16 +1076,16 @@ void launch_gemm(int R, int blocks_rows, hipStream_t stream, const float *in, in
     hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
 }
 
-template <int NT>
-void launch_gemm_bf16(int R, hipStream_t stream, const float *in, int Kdim, const bf16x8 *Wp, const int *pairs,
-                      int ld, int KV, int n_rows, int Ndim, const int *perm, const unsigned *row_mask, float *out) {
+template <int NT, bool IO16>
+void launch_gemm_bf16(int R, hipStream_t stream, const void *in, int Kdim, const bf16x8 *Wp, const int *pairs,
+                      int ld, int KV, int n_rows, int Ndim, const int *perm, const unsigned *row_mask, void *out) {
   auto grid = [&](int r) { return dim3(ceil_div(n_rows, 4 * r * 16)); };
   if (R == 1)
-    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 1>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 1, IO16>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
   else if (R == 2)
-    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 2>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 2, IO16>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
   else
-    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+    hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 4, IO16>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
 }
 
 }  // namespace
@@ -1249,9 +1309,9 @@ BFHIP_EXPORT int bfhip_spconv_gemm(const float *in, const float *W, const int32_
 // Same contract as bfhip_spconv_gemm with bf16 MFMA inputs (features/weights rounded to bf16 on load,
 // fp32 accumulate and output): the bf16 configs (the reference runs spconv in half precision under AMP).
 // Requires Kdim % 8 == 0; other shapes are rejected (use the fp32 entry point).
-BFHIP_EXPORT int bfhip_spconv_gemm_bf16(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
+BFHIP_EXPORT int bfhip_spconv_gemm_bf16(const void *in, const float *W, const int32_t *pairs, int ld, int KV,
                                         int n_rows, int Cin, int Cout, int transpose, int flip,
-                                        const int32_t *perm, const uint32_t *row_mask, float *out,
+                                        const int32_t *perm, const uint32_t *row_mask, void *out, int io_bf16,
                                         void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(KV > 0 && KV <= 32 && Cin > 0 && Cout > 0 && n_rows >= 0 && ld >= n_rows, "spconv_gemm_bf16: bad sizes");
@@ -1270,11 +1330,20 @@ BFHIP_EXPORT int bfhip_spconv_gemm_bf16(const float *in, const float *W, const i
                      flip, CC32, NT, Wp);
   int R = n_rows >= 262144 ? 4 : (n_rows >= 65536 ? 2 : 1);
   const bf16x8 *wp = (const bf16x8 *)Wp;
-  switch (NT) {
-    case 1: launch_gemm_bf16<1>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
-    case 2: launch_gemm_bf16<2>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
-    case 4: launch_gemm_bf16<4>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
-    default: launch_gemm_bf16<8>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+  if (io_bf16) {
+    switch (NT) {
+      case 1: launch_gemm_bf16<1, true>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      case 2: launch_gemm_bf16<2, true>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      case 4: launch_gemm_bf16<4, true>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      default: launch_gemm_bf16<8, true>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+    }
+  } else {
+    switch (NT) {
+      case 1: launch_gemm_bf16<1, false>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      case 2: launch_gemm_bf16<2, false>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      case 4: launch_gemm_bf16<4, false>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+      default: launch_gemm_bf16<8, false>(R, stream, in, Kdim, wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out); break;
+    }
   }
   prof_end(&ps);
   return check_launch("spconv_gemm_bf16");
@@ -1297,8 +1366,8 @@ BFHIP_EXPORT size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout
   return align_up((size_t)S * KV * Cin * Cout * sizeof(float), 256) + 256;
 }
 
-BFHIP_EXPORT int bfhip_spconv_wgrad(const float *in, const float *dout, const int32_t *pairs, int ld, int KV,
-                                    int n_rows, int Cin, int Cout, const int32_t *perm, float *dW,
+BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int32_t *pairs, int ld, int KV,
+                                    int n_rows, int Cin, int Cout, const int32_t *perm, float *dW, int io_bf16,
                                     void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(KV > 0 && Cin > 0 && Cout > 0 && n_rows >= 0 && ld >= n_rows, "spconv_wgrad: bad sizes");
@@ -1309,6 +1378,7 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const float *in, const float *dout, const in
   }
   BFHIP_REQUIRE(in && dout && pairs, "spconv_wgrad: null pointer");
   const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)dout % 16 == 0);
+  BFHIP_REQUIRE(!io_bf16 || vec, "spconv_wgrad: bf16 features need channel counts that are multiples of 4 (Cin=%d Cout=%d)", Cin, Cout);
   int GI = vec ? (Cin + 63) / 64 : (Cin + 31) / 32, GJ = (Cout + 63) / 64;
   int S = wgrad_splits(KV, (Cin + 63) / 64, GJ, n_rows);
   if (workspace_bytes < bfhip_spconv_wgrad_workspace_bytes(KV, Cin, Cout, n_rows) || !workspace) { set_error("spconv_wgrad: workspace too small"); return BFHIP_E_WORKSPACE; }
@@ -1317,18 +1387,20 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const float *in, const float *dout, const in
   ProfScope ps;
   prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
   const bool packed = vec && Cin == Cout && (Cin == 16 || Cin == 32) && perm == nullptr;
-  if (packed && Cin == 16)
-    hipLaunchKernelGGL(spconv_wgrad_packed_kernel<4>, dim3(ceil_div((long long)KV * S * 64, 256)), dim3(256), 0, stream, in, dout,
-                       pairs, ld, KV, n_rows, S, partial);
-  else if (packed)
-    hipLaunchKernelGGL(spconv_wgrad_packed_kernel<2>, dim3(ceil_div((long long)KV * S * 64, 256)), dim3(256), 0, stream, in, dout,
-                       pairs, ld, KV, n_rows, S, partial);
-  else if (vec)
-    hipLaunchKernelGGL(spconv_wgrad64_kernel, dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
-                       pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
-  else
-    hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, in, Cin, dout, Cout,
+  const dim3 pgrid(ceil_div((long long)KV * S * 64, 256)), wgrid(ceil_div(waves * 64, 256));
+  if (packed && Cin == 16) {
+    if (io_bf16) hipLaunchKernelGGL((spconv_wgrad_packed_kernel<4, true>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
+    else hipLaunchKernelGGL((spconv_wgrad_packed_kernel<4, false>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
+  } else if (packed) {
+    if (io_bf16) hipLaunchKernelGGL((spconv_wgrad_packed_kernel<2, true>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
+    else hipLaunchKernelGGL((spconv_wgrad_packed_kernel<2, false>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
+  } else if (vec) {
+    if (io_bf16) hipLaunchKernelGGL(spconv_wgrad64_kernel<true>, wgrid, dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
+    else hipLaunchKernelGGL(spconv_wgrad64_kernel<false>, wgrid, dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
+  } else {
+    hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), wgrid, dim3(256), 0, stream, (const float *)in, Cin, (const float *)dout, Cout,
                        pairs, ld, KV, n_rows, S, GI, GJ, partial);
+  }
   prof_end(&ps);  // the events bracket the dominant kernel only, so their average matches rocprof's for that kernel
   long long total = (long long)KV * Cin * Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, partial, S, KV, Cin, Cout, dW);

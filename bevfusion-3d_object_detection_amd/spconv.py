@@ -129,17 +129,34 @@ def _bf16_ok(weight, transpose):
     return kdim % 8 == 0 and ndim in (16, 32, 64, 128) or (kdim % 8 == 0 and ndim <= 128 and (ndim + 15) // 16 in (1, 2, 4, 8))
 
 
-def _gemm(inp, weight, pairs, n_rows, transpose, flip, perm=None, row_mask=None, bf16=False):
+# features stored in bf16 between the sparse layers under bf16 autocast (half the gather traffic; the reference's spconv
+# keeps fp16 features under AMP).  BFHIP_SPCONV_BF16_FEATURES=0 keeps fp32 storage with bf16-rounded MFMA inputs.
+BF16_FEATURES = os.environ.get("BFHIP_SPCONV_BF16_FEATURES", "1") == "1"
+
+
+def _io16_ok(weight, transpose):
+    """bf16 in / bf16 out needs the MFMA path (K % 8 == 0) and 16-byte aligned rows on both sides."""
+    cout, cin = weight.shape[0], weight.shape[-1]
+    kdim, ndim = (cout, cin) if transpose else (cin, cout)
+    return _bf16_ok(weight, transpose) and kdim % 8 == 0 and ndim % 8 == 0
+
+
+def _gemm(inp, weight, pairs, n_rows, transpose, flip, perm=None, row_mask=None, bf16=False, io16=False):
     cout, cin = weight.shape[0], weight.shape[-1]
     kv = pairs.shape[0]
-    out = torch.empty((n_rows, cin if transpose else cout), dtype=torch.float32, device=inp.device)
+    out = torch.empty((n_rows, cin if transpose else cout), dtype=torch.bfloat16 if io16 else torch.float32,
+                      device=inp.device)
     lib = _lib.load()
     ws = _workspace(inp.device, lib.bfhip_spconv_workspace_bytes(kv, cin, cout), "gemm")
-    fn = lib.bfhip_spconv_gemm_bf16 if (bf16 and _bf16_ok(weight, transpose)) else lib.bfhip_spconv_gemm
+    args = (_lib.ptr(inp), _lib.ptr(weight), _lib.ptr(pairs), pairs.shape[1], kv, n_rows, cin, cout, 1 if transpose else 0,
+            1 if flip else 0, _lib.ptr(perm), _lib.ptr(row_mask), _lib.ptr(out))
+    tail = (_lib.ptr(ws), ws.numel(), _lib.stream_of(inp))
     with torch.cuda.device(inp.device):
-        rc = fn(_lib.ptr(inp), _lib.ptr(weight), _lib.ptr(pairs), pairs.shape[1], kv, n_rows, cin,
-                                   cout, 1 if transpose else 0, 1 if flip else 0, _lib.ptr(perm), _lib.ptr(row_mask),
-                                   _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_of(inp))
+        if bf16 and _bf16_ok(weight, transpose):
+            rc = lib.bfhip_spconv_gemm_bf16(*args, 1 if io16 else 0, *tail)
+        else:
+            assert not io16
+            rc = lib.bfhip_spconv_gemm(*args, *tail)
     _lib.check(rc, "spconv_gemm")
     return out
 
@@ -149,13 +166,19 @@ class _SparseConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, features, weight, data, n_in):
-        # under bf16 autocast the MFMA inputs are rounded to bf16 (fp32 accumulate, fp32 features in HBM), as the
-        # reference's spconv runs in half precision under AMP; index paths and wgrad stay fp32
+        # under bf16 autocast the MFMA inputs are bf16 (fp32 accumulate), as the reference's spconv runs in half precision
+        # under AMP; with BF16_FEATURES the activations between the layers are stored in bf16 too.  Index paths and the
+        # weight gradient's accumulation stay fp32.
         ctx.bf16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
-        features = features.contiguous().float()
         w = weight.contiguous().float()
+        io16 = ctx.bf16 and BF16_FEATURES and _io16_ok(w, False) and _io16_ok(w, True)
+        ctx.io16 = io16
+        features = features.contiguous()
+        features = features.to(torch.bfloat16) if io16 else features.float()
         out = _gemm(features, w, data.pair_fwd, data.pair_fwd.shape[1], False, False, data.perm_fwd, data.mask_fwd,
-                    bf16=ctx.bf16)
+                    bf16=ctx.bf16, io16=io16)
+        if ctx.bf16 and BF16_FEATURES and not io16:
+            out = out.to(torch.bfloat16)  # narrow first layer (5 -> 16): fp32 kernel, bf16 hand-over
         ctx.save_for_backward(features, w)
         ctx.data = data
         ctx.n_in = n_in
@@ -165,15 +188,19 @@ class _SparseConvFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         features, w = ctx.saved_tensors
         data = ctx.data
-        grad_out = grad_out.contiguous().float()
+        io16 = ctx.io16
+        grad_out = grad_out.contiguous()
+        grad_out = grad_out.to(torch.bfloat16) if io16 else grad_out.float()
         d_feat = d_w = None
         if ctx.needs_input_grad[0]:
             if data.is_subm:
                 # SubM: pair_fwd doubles as the backward table with flipped offsets; rows with equal masks stay
                 # adjacent under perm_fwd (the flip permutes mask bits), the per-wave masks are recomputed
-                d_feat = _gemm(grad_out, w, data.pair_fwd, ctx.n_in, True, True, data.perm_fwd, data.mask_fwd, bf16=ctx.bf16)
+                d_feat = _gemm(grad_out, w, data.pair_fwd, ctx.n_in, True, True, data.perm_fwd, data.mask_fwd, bf16=ctx.bf16,
+                               io16=io16)
             else:
-                d_feat = _gemm(grad_out, w, data.pair_bwd, ctx.n_in, True, False, data.perm_bwd, data.mask_bwd, bf16=ctx.bf16)
+                d_feat = _gemm(grad_out, w, data.pair_bwd, ctx.n_in, True, False, data.perm_bwd, data.mask_bwd, bf16=ctx.bf16,
+                               io16=io16)
         if ctx.needs_input_grad[1]:
             cout, cin = w.shape[0], w.shape[-1]
             kv = data.pair_fwd.shape[0]
@@ -183,7 +210,7 @@ class _SparseConvFunction(torch.autograd.Function):
             ws = _workspace(w.device, lib.bfhip_spconv_wgrad_workspace_bytes(kv, cin, cout, n_out), "wgrad")
             with torch.cuda.device(w.device):
                 rc = lib.bfhip_spconv_wgrad(_lib.ptr(features), _lib.ptr(grad_out), _lib.ptr(data.pair_fwd), n_out, kv,
-                                            n_out, cin, cout, None, _lib.ptr(d_w), _lib.ptr(ws),
+                                            n_out, cin, cout, None, _lib.ptr(d_w), 1 if io16 else 0, _lib.ptr(ws),
                                             ws.numel(), _lib.stream_of(w))
             _lib.check(rc, "spconv_wgrad")
         return d_feat, d_w, None, None
@@ -350,6 +377,17 @@ class BatchNorm1dAct(nn.BatchNorm1d):
 
     def forward(self, x, residual=None, relu=False):
         C = x.shape[1] if x.dim() == 2 else 0
+        if (FUSED_BN1D and self.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.shape[0] > 1
+                and self.affine and self.track_running_stats and self.momentum is not None and C % 8 == 0):
+            # bf16 feature matrices: the channels-last BN kernels (csrc/bn2d.hip) on the [N, C, 1, 1] view
+            from . import bn2d
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            N = x.shape[0]
+            res = residual.contiguous().view(N, C, 1, 1) if residual is not None else None
+            y = bn2d._apply(x.contiguous().view(N, C, 1, 1), res, self.weight, self.bias, self.running_mean, self.running_var,
+                            self.eps, self.momentum, relu)
+            return y.view(N, C)
         fused = (FUSED_BN1D and self.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 1
                  and self.affine and self.track_running_stats and self.momentum is not None
                  and C % 4 == 0 and C <= 256 and 256 % C == 0)

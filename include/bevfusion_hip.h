@@ -232,16 +232,18 @@ int bfhip_spconv_gemm(const float *in, const float *W, const int32_t *pairs, int
                       int n_rows, int Cin, int Cout, int transpose, int flip, const int32_t *perm,
                       const uint32_t *row_mask, float *out, void *workspace, size_t workspace_bytes,
                       void *stream);
-/* bf16-input variant of bfhip_spconv_gemm (same arguments and workspace size): features and weights are rounded
- * to bf16 on load, products accumulate in fp32, output fp32.  For the bf16 configs (the reference runs spconv in
- * half precision under AMP).  Requires K % 8 == 0. */
-int bfhip_spconv_gemm_bf16(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
+/* bf16-MFMA variant of bfhip_spconv_gemm (same workspace size): features and weights enter the MFMA as bf16, products
+ * accumulate in fp32.  io_bf16 = 0: features f32 (rounded on load), output f32.  io_bf16 = 1: features STORED in bf16
+ * (the gathered 16-byte row segments are the MFMA operand as they are: half the gather traffic) and the output rounded
+ * to bf16 once -- the reference runs spconv in half precision under AMP.  Requires K % 8 == 0. */
+int bfhip_spconv_gemm_bf16(const void *in, const float *W, const int32_t *pairs, int ld, int KV,
                            int n_rows, int Cin, int Cout, int transpose, int flip, const int32_t *perm,
-                           const uint32_t *row_mask, float *out, void *workspace, size_t workspace_bytes,
+                           const uint32_t *row_mask, void *out, int io_bf16, void *workspace, size_t workspace_bytes,
                            void *stream);
 size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout, int n_rows);
-int bfhip_spconv_wgrad(const float *in, const float *dout, const int32_t *pairs, int ld, int KV,
-                       int n_rows, int Cin, int Cout, const int32_t *perm, float *dW, void *workspace,
+/* io_bf16 = 1: `in` and `dout` are bf16 feature matrices (widened on load; Cin, Cout multiples of 4); dW is always f32 */
+int bfhip_spconv_wgrad(const void *in, const void *dout, const int32_t *pairs, int ld, int KV,
+                       int n_rows, int Cin, int Cout, const int32_t *perm, float *dW, int io_bf16, void *workspace,
                        size_t workspace_bytes, void *stream);
 int bfhip_sparse_to_bev(const float *feats, const int32_t *indices, int N, int C, int B, int X,
                         int Y, int Z, float *out, void *stream);

@@ -188,10 +188,14 @@ def test_encoder_layer_vs_oracle_end_to_end(dev):
     assert rel_err(y.features.detach().cpu().numpy(), f2) < TOL
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 64), (128, 128)])
-def test_conv_bf16_autocast_vs_oracle(dev, cin, cout):
-    """Under bf16 autocast the gather-GEMM rounds its MFMA inputs to bf16 (fp32 accumulate): within the 1e-2 rel
-    bf16 tolerance of the north star against the fp64-accumulated oracle; wgrad stays fp32."""
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 64), (128, 128), (16, 16), (32, 32)])
+@pytest.mark.parametrize("bf16_features", [True, False])
+def test_conv_bf16_autocast_vs_oracle(dev, cin, cout, bf16_features, monkeypatch):
+    """Under bf16 autocast the gather-GEMM feeds the MFMA with bf16 (fp32 accumulate) and, with BF16_FEATURES, stores the
+    activations in bf16: within the 1e-2 rel bf16 tolerance of the north star against the fp64-accumulated oracle.  The
+    weight gradient accumulates in fp32 from the (bf16-rounded) saved features and output gradient."""
+    from bevfusion_amd import spconv as sp
+    monkeypatch.setattr(sp, "BF16_FEATURES", bf16_features)
     B, shape, n = 2, (40, 36, 9), 6000
     idx, feats = random_sparse(B, shape, n, cin, seed=cin * 3 + cout)
     conv = SubMConv3d(cin, cout, 3, padding=1, bias=False).to(dev)
@@ -199,16 +203,50 @@ def test_conv_bf16_autocast_vs_oracle(dev, cin, cout):
     x = SparseConvTensor(torch.from_numpy(feats).to(dev).requires_grad_(True), torch.from_numpy(idx).to(dev), shape, B)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = conv(x)
-    assert out.features.dtype == torch.float32
+    assert out.features.dtype == (torch.bfloat16 if bf16_features else torch.float32)
     pair = oracle.rulebook_subm(idx, shape, 3)
     want = oracle.spconv_fwd(feats, w, pair)
-    err = rel_err(out.features.detach().cpu().numpy(), want)
+    err = rel_err(out.features.detach().float().cpu().numpy(), want)
     assert 1e-6 < err < 1e-2, err     # really the bf16 path (not bit-identical to fp32), inside the bf16 budget
     g = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(1)).to(dev)
-    out.features.backward(g)
+    out.features.backward(g.to(out.features.dtype))
     d_in, d_w = oracle.spconv_bwd(feats, w, g.cpu().numpy(), pair)
+    assert x.features.grad.dtype == torch.float32
     assert rel_err(x.features.grad.cpu().numpy(), d_in) < 1e-2
-    assert rel_err(conv.weight.grad.cpu().numpy(), d_w) < TOL     # wgrad is fp32
+    assert rel_err(conv.weight.grad.cpu().numpy(), d_w) < (1e-2 if bf16_features else TOL)  # fp32 accumulate either way
+
+
+def test_encoder_bf16_features_vs_fp32_storage(dev, monkeypatch):
+    """The whole sparse encoder (21 convs + BN) three ways: fp32; bf16 autocast with fp32 feature storage; bf16 autocast
+    with bf16 feature storage.  The BEV output of both autocast modes stays within the bf16 budget of the fp32 run, and
+    bf16 storage does not degrade the weight gradients relative to fp32 storage (cosine to the fp32 gradients), even for
+    the first layer, 21 layers upstream of the loss."""
+    from bevfusion_amd import spconv as sp
+    from bevfusion_amd.sparse_encoder import BEVFusionSparseEncoder
+    B, shape, n = 2, (96, 96, 41), 5000
+    idx, feats = random_sparse(B, shape, n, 5, seed=11)
+    outs, grads = {}, {}
+    for mode in ("fp32", "amp_f32_store", "amp_bf16_store"):
+        monkeypatch.setattr(sp, "BF16_FEATURES", mode == "amp_bf16_store")
+        torch.manual_seed(0)
+        enc = BEVFusionSparseEncoder(in_channels=5, sparse_shape=list(shape), norm_cfg=dict(type="BN1d", eps=0.001, momentum=0.01),
+                                     encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                                     encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, (1, 1, 0)), (0, 0)),
+                                     block_type="basicblock").to(dev).train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32"):
+            bev = enc(torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev), B)
+        assert bev.dtype == torch.float32  # to_bev() default: the reference's fp32 NCHW map
+        bev.square().mean().backward()
+        outs[mode] = bev.detach()
+        grads[mode] = [p.grad.detach().double() for p in enc.parameters() if p.dim() == 5]
+    ref = outs["fp32"].cpu().numpy()
+    assert rel_err(outs["amp_f32_store"].cpu().numpy(), ref) < 5e-2
+    assert rel_err(outs["amp_bf16_store"].cpu().numpy(), ref) < 5e-2
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))  # noqa: E731
+    for i in (0, len(grads["fp32"]) // 2, len(grads["fp32"]) - 1):
+        c32 = cos(grads["amp_f32_store"][i], grads["fp32"][i])
+        c16 = cos(grads["amp_bf16_store"][i], grads["fp32"][i])
+        assert c16 > 0.9 and c16 > c32 - 0.03, (i, c32, c16)
 
 
 @pytest.mark.parametrize("C,res,relu", [(16, False, True), (32, True, True), (64, False, False), (128, True, True)])
@@ -216,6 +254,7 @@ def test_fused_bn1d_matches_torch(dev, C, res, relu):
     """BatchNorm1dAct (csrc/bn1d.hip) vs torch BatchNorm1d [+ add] [+ relu]: outputs, running stats and all gradients."""
     from bevfusion_amd.spconv import BatchNorm1dAct
     N = 30011
+    torch.manual_seed(C)  # the affine parameters below come from the global generator
     g = torch.Generator().manual_seed(C)
     x = (torch.randn(N, C, generator=g) * 2 + 0.5).to(dev)
     r = torch.randn(N, C, generator=g).to(dev) if res else None
@@ -240,12 +279,17 @@ def test_fused_bn1d_matches_torch(dev, C, res, relu):
     go = torch.randn(N, C, generator=g).to(dev)
     y.backward(go)
     yr.backward(go)
-    # dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N): cancellation -> compare on the max-normalised scale
-    assert rel_err(x1.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 1e-4
+    # dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N): cancellation -> compare on the max-normalised scale.  Elements whose
+    # pre-activation sits within rounding of the ReLU kink may be switched on in one implementation and off in the other
+    # (1e-8 vs exactly 0): their gradient is excluded from the comparison.
+    kink = ((y.detach().abs() < 1e-6) | (yr.detach().abs() < 1e-6)) if relu else torch.zeros_like(y, dtype=torch.bool)
+    g1 = torch.where(kink & ((y.detach() > 0) != (yr.detach() > 0)), x2.grad, x1.grad)
+    assert rel_err(g1.cpu().numpy(), x2.grad.cpu().numpy()) < 1e-4
     assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
     if res:
-        assert torch.allclose(r1.grad, r2.grad, rtol=1e-5, atol=1e-6)
+        same_side = ~(kink & ((y.detach() > 0) != (yr.detach() > 0)))
+        assert torch.allclose(r1.grad[same_side], r2.grad[same_side], rtol=1e-5, atol=1e-6)
     # eval mode and unsupported widths fall back to torch's own kernels with identical semantics
     bn.eval(); ref.eval()
     assert torch.allclose(bn(x, relu=relu), torch.relu(ref(x)) if relu else ref(x), rtol=1e-5, atol=1e-5)
