@@ -455,10 +455,64 @@ __global__ __launch_bounds__(1024) void query_losses_kernel(const float *__restr
   if (threadIdx.x == 0) { out[0] = (float)cls_sum; out[1] = (float)box_sum; }
 }
 
+
+// ------------------------------------------------------------------------------------ circle NMS
+// mmdet3d/models/layers/box3d_nms.py:186-228: greedy, highest score first; j is suppressed when the SQUARED centre distance is
+// <= thresh (the reference compares the squared distance with the radius as given; kept).  One workgroup: rank by
+// counting (ties -> lower index first), then the sequential sweep with the inner loop spread over the threads.
+__global__ __launch_bounds__(256) void circle_nms_kernel(const float *__restrict__ dets, int n, float thresh,
+                                                         int post_max, int *__restrict__ keep, int *__restrict__ n_keep) {
+  extern __shared__ int sm_i[];
+  int *order = sm_i;                 // [n] index of the i-th highest score
+  int *supp = order + n;             // [n] by sorted position
+  float *sx = (float *)(supp + n), *sy = sx + n;  // [n] centres in sorted order
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float si = dets[i * 3 + 2];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float sj = dets[j * 3 + 2];
+      rank += (sj > si) || (sj == si && j < i);
+    }
+    order[rank] = i;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    supp[i] = 0;
+    sx[i] = dets[order[i] * 3];
+    sy[i] = dets[order[i] * 3 + 1];
+  }
+  __syncthreads();
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    if (supp[i]) continue;  // uniform: every thread reads the same LDS word after the barrier below
+    if (threadIdx.x == 0 && kept < post_max) keep[kept] = order[i];
+    ++kept;
+    const float xi = sx[i], yi = sy[i];
+    for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+      const float dx = xi - sx[j], dy = yi - sy[j];
+      if (dx * dx + dy * dy <= thresh) supp[j] = 1;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_keep = kept < post_max ? kept : post_max;
+}
+
 }  // namespace
 }  // namespace bfhip
 
 using namespace bfhip;
+
+BFHIP_EXPORT int bfhip_circle_nms(const float *dets, int n, float thresh, int post_max_size, int32_t *keep,
+                                  int32_t *n_keep, void *stream) {
+  BFHIP_REQUIRE(n_keep && (n == 0 || (dets && keep)) && n >= 0 && n <= 4096 && post_max_size >= 0, "circle_nms: bad arguments (n <= 4096)");
+  if (n == 0) {
+    if (hipMemsetAsync(n_keep, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return check_launch("circle_nms memset");
+    return BFHIP_OK;
+  }
+  hipLaunchKernelGGL(circle_nms_kernel, dim3(1), dim3(256), (size_t)n * 16, (hipStream_t)stream, dets, n, thresh, post_max_size,
+                     keep, n_keep);
+  return check_launch("circle_nms");
+}
 
 BFHIP_EXPORT int bfhip_decode_boxes(const float *center, const float *height, const float *dim, const float *rot,
                                     const float *vel, int B, int P, int ld, int p_off,

@@ -490,9 +490,30 @@ class BEVFusionHead(nn.Module):
         score = score * preds["query_heatmap_score"] * one_hot
         vel = preds["vel"][..., -P:] if "vel" in preds else None
         nms_type = (self.test_cfg or {}).get("nms_type", None)
-        assert nms_type is None, "only nms_type=None (the reference's nuScenes setting) is implemented"
+        assert nms_type in (None, "circle"), "nms_type None (the reference's nuScenes setting) and 'circle' are implemented"
         rets = self.bbox_coder.decode(score, preds["rot"][..., -P:], preds["dim"][..., -P:], preds["center"][..., -P:],
                                       preds["height"][..., -P:], vel, filter=True)
+        if nms_type == "circle":
+            from .head_targets import circle_nms
+            # nuScenes tasks (:358-378): classes 0-7 untouched, pedestrians (8) and traffic cones (9) with radius 0.175
+            tasks = [(list(range(8)), -1.0), ([8], 0.175), ([9], 0.175)] if (self.test_cfg or {}).get("dataset") == "nuScenes" \
+                else [([0], 0.7), ([1], 0.7), ([2], 0.7)]
+            out = []
+            for r in rets:
+                boxes, scores, labels = r["bboxes"], r["scores"], r["labels"]
+                keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+                for classes, radius in tasks:
+                    task_mask = torch.zeros_like(keep_mask)
+                    for c in classes:
+                        task_mask |= labels == c
+                    if radius > 0:
+                        idx = torch.where(task_mask)[0]
+                        kept = circle_nms(torch.cat([boxes[idx, :2], scores[idx, None]], dim=1), radius)
+                        keep_mask[idx[kept]] = True
+                    else:
+                        keep_mask |= task_mask
+                out.append(dict(bboxes=boxes[keep_mask], scores=scores[keep_mask], labels=labels[keep_mask]))
+            rets = out
         return [dict(bboxes_3d=r["bboxes"], scores_3d=r["scores"], labels_3d=r["labels"].int()) for r in rets]
 
     def predict(self, batch_feats, batch_input_metas=None):

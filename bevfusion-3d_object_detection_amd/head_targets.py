@@ -200,6 +200,62 @@ class HungarianAssigner3D:
         return AssignResult(G, gt_inds, max_overlaps, labels=labels)
 
 
+@MODELS.register_module()
+class HeuristicAssigner3D:
+    """BF/utils.py:154-223: every GT box takes its nearest prediction in BEV (same class only when query labels are given);
+    a prediction claimed by several GT boxes keeps the closest one (the lower GT index on ties).  Vectorised on the device:
+    the reference walks the GT boxes in a Python loop with a device read per step."""
+
+    def __init__(self, dist_thre=100, iou_calculator=dict(type="BboxOverlaps3D")):
+        self.dist_thre = dist_thre
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, query_labels=None):
+        P, G = bboxes.size(0), gt_bboxes.size(0)
+        dev = bboxes.device
+        inds = torch.zeros(P, dtype=torch.long, device=dev)
+        labels = torch.full((P,), -1, dtype=torch.long, device=dev)
+        overlaps = torch.zeros(P, dtype=torch.float32, device=dev)
+        if G == 0 or P == 0:
+            return AssignResult(G, inds, overlaps, labels=labels)
+        gt_bboxes = gt_bboxes.to(dev, torch.float32)
+        dist = torch.norm(bboxes[:, 0:2][None, :, :] - gt_bboxes[:, 0:2][:, None, :], dim=-1)  # [G, P]
+        if query_labels is not None:
+            dist = dist + (query_labels[None] != gt_labels[:, None]).to(dist.dtype) * self.dist_thre
+        near_val, near = dist.min(1)                                   # per GT: its nearest prediction
+        ok = near_val <= self.dist_thre
+        big = torch.full((P,), 10000.0, dtype=dist.dtype, device=dev)
+        best = big.scatter_reduce(0, near[ok], near_val[ok], reduce="amin", include_self=True)
+        wins = ok & (near_val == best[near]) & (near_val < 10000.0)    # candidates at the winning distance
+        g_idx = torch.arange(G, device=dev)
+        first = torch.full((P,), G, dtype=torch.long, device=dev).scatter_reduce(0, near[wins], g_idx[wins], reduce="amin",
+                                                                                 include_self=True)
+        matched = first < G
+        inds = torch.where(matched, first + 1, inds)
+        if gt_labels is not None:
+            labels = torch.where(matched, gt_labels.to(dev).long()[first.clamp(max=G - 1)], labels)
+        # IoU of the matched pairs (BF/utils.py:218-221)
+        gtl = (gt_labels if gt_labels is not None else torch.zeros(G, device=dev)).to(dev, torch.int32).contiguous()[None]
+        n_gt = torch.tensor([G], dtype=torch.int32).to(dev)
+        zeros = torch.zeros(1, 1, P, dtype=torch.float32, device=dev)
+        w = dict(cls_w=0.0, alpha=0.25, gamma=2.0, eps=1e-12, reg_w=0.0, iou_w=1.0)
+        _, iou, _, _ = assign_batch(_f32c(bboxes)[None], zeros, gt_bboxes.contiguous()[None], gtl.clamp(min=0, max=0), n_gt,
+                                    [-1e4, -1e4, -1e4, 1e4, 1e4, 1e4], w)
+        overlaps = torch.where(matched, iou[0].gather(1, first.clamp(max=G - 1)[:, None])[:, 0], overlaps)
+        return AssignResult(G, inds, overlaps, labels=labels)
+
+
+def circle_nms(dets, thresh, post_max_size=83):
+    """mmdet3d/models/layers/box3d_nms.py:186-228 on the device: dets [N, 3] = (x, y, score) -> kept indices (int64, highest
+    score first).  One host read (the number of kept boxes), as the reference returns a Python list."""
+    n = int(dets.shape[0])
+    d = _f32c(dets)
+    keep = torch.empty(max(min(n, post_max_size), 1), dtype=torch.int32, device=d.device)
+    count = torch.empty(1, dtype=torch.int32, device=d.device)
+    _lib.call("bfhip_circle_nms", _lib.ptr(d) if n else None, n, float(thresh), int(post_max_size), _lib.ptr(keep), _lib.ptr(count),
+              _lib.stream_of(d))
+    return keep[:int(count.item())].long()
+
+
 # ----------------------------------------------------------------------------------------------- targets
 def build_targets(assigned, iou, gt_boxes, gt_labels, num_classes, code_size, pc_range, out_size_factor, voxel_size,
                   pos_weight=-1):

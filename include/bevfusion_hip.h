@@ -393,6 +393,11 @@ size_t bfhip_gaussian_focal_loss_workspace_bytes(long long n);
 int bfhip_gaussian_focal_loss(const float *logits, const float *target, long long n, float clip_eps,
                               float *loss_sum_npos, float *grad, void *workspace, size_t workspace_bytes,
                               void *stream);
+/* circle NMS (mmdet3d/models/layers/box3d_nms.py:186-228, called from BEVFusionHead.predict_by_feat :399-413 on the CPU):
+ * dets f32[n,3] = (x, y, score); keep i32[min(n, post_max_size)] receives the kept indices, highest score first;
+ * n_keep i32[1].  n <= 4096. */
+int bfhip_circle_nms(const float *dets, int n, float thresh, int post_max_size, int32_t *keep, int32_t *n_keep,
+                     void *stream);
 int bfhip_query_losses(const float *cls_logits, const int32_t *labels, const float *label_weights,
                        const float *box_pred, const float *bbox_targets, const float *bbox_weights,
                        const float *code_weights, int B, int C, int P, int K, int ld, int p_off, float gamma,

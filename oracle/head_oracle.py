@@ -310,3 +310,48 @@ def sigmoid_focal_loss(logits, labels, weights, gamma=2.0, alpha=0.25, avg_facto
 def l1_loss(pred, target, weight, avg_factor=1.0):
     """mmdet L1Loss(reduction='mean') with avg_factor."""
     return (np.abs(np.asarray(pred, np.float64) - np.asarray(target, np.float64)) * np.asarray(weight, np.float64)).sum() / avg_factor
+
+
+# ------------------------------------------------------------------------------ inference post-processing
+def circle_nms(dets, thresh, post_max_size=83):
+    """mmdet3d/models/layers/box3d_nms.py:186-228 (numpy in the reference too; the squared distance is compared with
+    `thresh` as given).  Ties in the score order resolve to the lower index first."""
+    dets = np.asarray(dets, np.float32)
+    x1, y1, scores = dets[:, 0], dets[:, 1], dets[:, 2]
+    order = np.lexsort((np.arange(len(scores)), -scores)).astype(np.int32)
+    n = len(dets)
+    suppressed = np.zeros(n, np.int32)
+    keep = []
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        keep.append(int(i))
+        for _j in range(_i + 1, n):
+            j = order[_j]
+            if suppressed[j]:
+                continue
+            dist = (x1[i] - x1[j]) ** 2 + (y1[i] - y1[j]) ** 2
+            if dist <= np.float32(thresh):
+                suppressed[j] = 1
+    return keep[:post_max_size] if post_max_size < len(keep) else keep
+
+
+def heuristic_assign(bboxes, gt_bboxes, gt_labels=None, query_labels=None, dist_thre=100.0):
+    """BF/utils.py:161-223 (HeuristicAssigner3D.assign) without the IoU of the matched pairs.
+    Returns assigned_gt_inds [P] (0 = background, g+1), assigned labels [P] (-1 = none)."""
+    b, g = np.asarray(bboxes, np.float32), np.asarray(gt_bboxes, np.float32)
+    P, G = len(b), len(g)
+    dist = np.linalg.norm(b[None, :, :2] - g[:, None, :2], axis=-1).astype(np.float32)  # [G, P]
+    if query_labels is not None:
+        dist = dist + (np.asarray(query_labels)[None] != np.asarray(gt_labels)[:, None]) * np.float32(dist_thre)
+    inds = np.zeros(P, np.int64)
+    vals = np.full(P, 10000.0, np.float32)
+    labs = np.full(P, -1, np.int64)
+    for i in range(G):
+        p = int(dist[i].argmin())
+        if dist[i, p] <= dist_thre and dist[i, p] < vals[p]:
+            vals[p] = dist[i, p]
+            inds[p] = i + 1
+            labs[p] = int(gt_labels[i]) if gt_labels is not None else -1
+    return inds, labs

@@ -244,3 +244,53 @@ def test_assigner_class_keeps_the_reference_call(dev):
     empty = a.assign(torch.from_numpy(pred).to(dev), torch.zeros(0, 9, device=dev), torch.zeros(0, dtype=torch.long, device=dev),
                      torch.from_numpy(logits).to(dev)[None], dict(point_cloud_range=PC))
     assert (empty.gt_inds == 0).all() and empty.max_overlaps is None
+
+
+def test_circle_nms_matches_oracle(dev):
+    rs = np.random.RandomState(3)
+    for n, thresh in ((0, 0.175), (1, 0.175), (57, 0.175), (200, 0.5), (700, 2.0)):
+        centres = rs.uniform(-5, 5, (max(n // 6, 1), 2))
+        xy = (centres[rs.randint(0, len(centres), n)] + rs.normal(0, 0.3, (n, 2))).astype(np.float32)
+        dets = np.concatenate([xy, rs.uniform(0, 1, (n, 1)).astype(np.float32)], 1) if n else np.zeros((0, 3), np.float32)
+        if n > 10:
+            dets[5, 2] = dets[9, 2]  # a score tie
+        want = ho.circle_nms(dets, thresh, post_max_size=83)
+        got = ht.circle_nms(torch.from_numpy(dets).to(dev), thresh, post_max_size=83).cpu().tolist()
+        assert got == want, (n, thresh)
+    if True:  # suppression really happens and the cap applies
+        assert len(ho.circle_nms(dets, 2.0, 83)) < 700 and len(ht.circle_nms(torch.from_numpy(dets).to(dev), 1e-9, 83)) == 83
+
+
+def test_heuristic_assigner_matches_oracle(dev):
+    boxes, labels, pred, logits = scene(7000, 30)
+    qlab = np.random.RandomState(0).randint(0, 10, len(pred))
+    qlab[:30] = labels  # so that some same-class matches exist
+    a = ht.HeuristicAssigner3D(dist_thre=100)
+    for use_labels in (False, True):
+        res = a.assign(torch.from_numpy(pred).to(dev), torch.from_numpy(boxes).to(dev), None, torch.from_numpy(labels).to(dev),
+                       torch.from_numpy(qlab).to(dev) if use_labels else None)
+        inds, labs = ho.heuristic_assign(pred, boxes, labels, qlab if use_labels else None, 100.0)
+        np.testing.assert_array_equal(res.gt_inds.cpu().numpy(), inds)
+        np.testing.assert_array_equal(res.labels.cpu().numpy(), labs)
+        m = inds > 0
+        iou = ho.bbox_overlaps_3d_lidar(pred[m][:, :7], boxes[inds[m] - 1][:, :7]).diagonal()
+        np.testing.assert_allclose(res.max_overlaps.cpu().numpy()[m], iou, atol=2e-4)
+        assert (res.max_overlaps.cpu().numpy()[~m] == 0).all()
+
+
+def test_predict_with_circle_nms(dev):
+    from bevfusion_amd.bevfusion import nuscenes_config
+    from bevfusion_amd.registry import MODELS
+    cfg = nuscenes_config(camera=False)["bbox_head"]
+    cfg["test_cfg"] = dict(cfg["test_cfg"], nms_type="circle")
+    torch.manual_seed(0)
+    head = MODELS.build(cfg).to(dev).eval()
+    with torch.no_grad():
+        feats = torch.randn(2, 512, 180, 180, device=dev)
+        plain = MODELS.build(nuscenes_config(camera=False)["bbox_head"]).to(dev).eval()
+        plain.load_state_dict(head.state_dict())
+        a, b = head.predict(feats), plain.predict(feats)
+    for ra, rb in zip(a, b):
+        assert ra["bboxes_3d"].shape[0] <= rb["bboxes_3d"].shape[0]
+        keep_other = rb["labels_3d"] < 8
+        assert int((ra["labels_3d"] < 8).sum()) == int(keep_other.sum())  # classes 0-7 are not suppressed
