@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
-    ap.add_argument("--workload", default="full", choices=["full", "lidar_only", "camera_only", "hotpath_v1", "dist_selftest"])
+    ap.add_argument("--workload", default="full", choices=["full", "lidar_only", "lidar_branch", "camera_only", "hotpath_v1", "dist_selftest"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --workload dist_selftest (CPU)")
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -302,6 +302,24 @@ class LidarOnly(_ModelWorkload):
     name = "lidar_only: hard voxelize + BEVFusionSparseEncoder + SECOND/SECONDFPN + TransFusion head fwd+bwd+AdamW, fp32"
 
 
+class LidarBranch(LidarOnly):
+    """BASELINE configs[1] read literally: ONLY hard voxelization + the 4-stage sparse encoder, forward + backward, fp32 --
+    no BEV backbone, head or optimizer around it (the gradient of a sum of squares of the BEV map drives the backward)."""
+    name = "lidar_branch: hard voxelize + voxel mean + BEVFusionSparseEncoder (21 sparse convs, fused BN1d) fwd+bwd, fp32"
+
+    def step(self):
+        for p in self._enc_params:
+            p.grad = None
+        bev = self.model.extract_pts_feat(self.inputs)
+        loss = bev.float().square().mean()
+        loss.backward()
+        return loss
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._enc_params = list(self.model.pts_middle_encoder.parameters())
+
+
 class CameraOnly(_ModelWorkload):
     """BASELINE configs[2]: ResNet-50 + LSS depth outer product + bev_pool to 180x180 (+ BEV backbone/head), bf16."""
     camera, lidar, amp = True, False, True
@@ -366,7 +384,7 @@ class DistSelfTest:
         return float(sum(p.grad.double().abs().sum() for p in self.tail.parameters() if p.grad is not None))
 
 
-WORKLOADS = {"dist_selftest": DistSelfTest, "full": FullModel, "lidar_only": LidarOnly, "camera_only": CameraOnly, "hotpath_v1": HotPathV1}
+WORKLOADS = {"dist_selftest": DistSelfTest, "full": FullModel, "lidar_only": LidarOnly, "lidar_branch": LidarBranch, "camera_only": CameraOnly, "hotpath_v1": HotPathV1}
 
 
 def main():
