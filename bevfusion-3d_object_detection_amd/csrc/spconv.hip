@@ -774,17 +774,19 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const void *__restr
                                                              int KV, int n_rows, int S, int GI, int GJ,
                                                              const int *__restrict__ perm,
                                                              float *__restrict__ partial) {
-  const int lane = threadIdx.x & 63;
-  long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long total = (long long)KV * S * GI * GJ;
-  if (wave >= total) return;
-  const int gj = (int)(wave % GJ); wave /= GJ;
-  const int gi = (int)(wave % GI); wave /= GI;
-  const int s = (int)(wave % S);
-  const int k = (int)(wave / S);
+  // workgroup = the 4 row splits s = 4*sg .. 4*sg+3 of one (offset k, 64-ci block gi, 64-co block gj): the four 64 x 64
+  // results are added through LDS in a fixed order and written once (a quarter of the partial-slab traffic)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int S4 = (S + 3) >> 2;
+  long long blk = blockIdx.x;
+  const int gj = (int)(blk % GJ); blk /= GJ;
+  const int gi = (int)(blk % GI); blk /= GI;
+  const int sg = (int)(blk % S4);
+  const int k = (int)(blk / S4);
+  const int s = sg * 4 + wv;
   const int la = lane & 15, lq = lane >> 4;
   const int rows_per = (((n_rows + S - 1) / S) + 63) & ~63;
-  const int r0 = s * rows_per, r1 = min(n_rows, r0 + rows_per);
+  const int r0 = s < S ? s * rows_per : 0, r1 = s < S ? min(n_rows, r0 + rows_per) : 0;
   const int ci = gi * 64 + la * 4, co = gj * 64 + la * 4;
   const bool ci_ok = ci < Cin, co_ok = co < Cout;  // Cin, Cout multiples of 4 (checked by the host)
   f32x4 acc[4][4];
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const void *__restr
   // (ballot + prefix popcount into a wave-private LDS list), so every MFMA K-step carries 4 real pairs instead
   // of ~50 % holes at the dense stages (and ~85 % at stage 1).
   __shared__ int2 s_list[4][64];
-  int2 *list = s_list[threadIdx.x >> 6];
+  int2 *list = s_list[wv];
   constexpr int U = 4;  // 16 pairs = 8 gathers in flight per group (U = 8 measured no faster: MFMA issue and gather latency add up at ~2 waves per SIMD)
   for (int chunk = r0; chunk < r1; chunk += 64) {
     const int row = chunk + lane;
@@ -843,20 +845,25 @@ __global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const void *__restr
     __builtin_amdgcn_wave_barrier();
   }
   // D layout: row = (lane>>4)*4 + i -> a (ci = 4a + c), col = lane&15 -> a' (co = 4a' + d)
-  float *dst = partial + ((size_t)s * KV + k) * Cin * Cout;
+  __shared__ float red[64 * 64];
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int cii = gi * 64 + (lq * 4 + i) * 4 + c;
-      if (cii < Cin) {
-        int coo = gj * 64 + la * 4;
-        if (coo < Cout) {
-          f32x4 v = (f32x4){acc[c][0][i], acc[c][1][i], acc[c][2][i], acc[c][3][i]};
-          *(f32x4 *)(dst + (size_t)cii * Cout + coo) = v;
+        for (int i = 0; i < 4; ++i) {
+          float *r = red + ((lq * 4 + i) * 4 + c) * 64 + la * 4;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) r[d] = (w == 0 ? 0.f : r[d]) + acc[c][d][i];
         }
-      }
     }
+    __syncthreads();
+  }
+  float *dst = partial + ((size_t)sg * KV + k) * Cin * Cout;
+  for (int e = threadIdx.x * 4; e < 64 * 64; e += 256 * 4) {
+    const int cii = gi * 64 + (e >> 6), coo = gj * 64 + (e & 63);
+    if (cii < Cin && coo < Cout) *(f32x4 *)(dst + (size_t)cii * Cout + coo) = *(const f32x4 *)(red + e);
+  }
 }
 
 // v3 for the narrow stages (Cin == Cout == C = 64 / R, R = 4 | 2): the 64 x 64 MFMA block of v2 is 1/16 (C = 16) or 1/4
@@ -870,22 +877,22 @@ __global__ __launch_bounds__(256) void spconv_wgrad_packed_kernel(const void *__
                                                                   const int *__restrict__ pairs, int ld, int KV,
                                                                   int n_rows, int S, float *__restrict__ partial) {
   constexpr int C = 64 / R, AV = 16 / R;  // channels, channel vectors per row group
-  const int lane = threadIdx.x & 63;
-  long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wave >= (long long)KV * S) return;
-  const int s = (int)(wave % S);
-  const int k = (int)(wave / S);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int S4 = (S + 3) >> 2;
+  const int sg = (int)(blockIdx.x % S4);   // workgroup = row splits 4*sg .. 4*sg+3 of offset k, summed through LDS
+  const int k = (int)(blockIdx.x / S4);
+  const int s = sg * 4 + wv;
   const int la = lane & 15, lq = lane >> 4;
   const int r = la / AV, a = la % AV;
   const int rows_per = (((n_rows + S - 1) / S) + 63) & ~63;
-  const int r0 = s * rows_per, r1 = min(n_rows, r0 + rows_per);
+  const int r0 = s < S ? s * rows_per : 0, r1 = s < S ? min(n_rows, r0 + rows_per) : 0;
   f32x4 acc[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __shared__ int2 s_list[4][64];
-  int2 *list = s_list[threadIdx.x >> 6];
+  int2 *list = s_list[wv];
   constexpr int U = 16 / R;  // K steps per 64-pair chunk (each consumes 4R pairs)
   for (int chunk = r0; chunk < r1; chunk += 64) {
     const int row = chunk + lane;
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_packed_kernel(const void *__
   // D_cd[m][n]: m = lq*4 + i = (row group m / AV, vector m % AV), n = la = (r', a').  The diagonal block of row group g sits
   // in lanes with r' == g and m / AV == g; group g's copy of element (vector a, vector a') is `g * step` lanes above group 0's.
   constexpr int step = 16 * (4 / R) + AV;
-  float *dst = partial + ((size_t)s * KV + k) * C * C;
+  __shared__ float red[4][C * C];
   const bool owner = lq < 4 / R && la < AV;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -947,9 +954,17 @@ __global__ __launch_bounds__(256) void spconv_wgrad_packed_kernel(const void *__
       }
       if (owner) {
         const int cii = ((lq * 4 + i) % AV) * 4 + c;  // input channel 4a + c with a = m % AV
-        *(f32x4 *)(dst + (size_t)cii * C + la * 4) = v;
+        *(f32x4 *)(red[wv] + cii * C + la * 4) = v;
       }
     }
+  __syncthreads();
+  float *dst = partial + ((size_t)sg * KV + k) * C * C;
+  for (int e = threadIdx.x * 4; e < C * C; e += 256 * 4) {
+    f32x4 t = *(const f32x4 *)(red[0] + e);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += *(const f32x4 *)(red[w] + e);  // fixed order
+    *(f32x4 *)(dst + e) = t;
+  }
 }
 
 // dW[co][k][ci] = sum_s partial[s][k][ci][co]   (fixed order -> deterministic)
@@ -1363,7 +1378,7 @@ static inline int wgrad_splits(int KV, int GI, int GJ, int n_rows) {
 BFHIP_EXPORT size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout, int n_rows) {
   int GI = (Cin + 63) / 64, GJ = (Cout + 63) / 64;
   int S = wgrad_splits(KV, GI, GJ, n_rows);
-  return align_up((size_t)S * KV * Cin * Cout * sizeof(float), 256) + 256;
+  return align_up((size_t)S * KV * Cin * Cout * sizeof(float), 256) + 256;  // the vector kernels use (S + 3) / 4 slabs of it
 }
 
 BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int32_t *pairs, int ld, int KV,
@@ -1387,7 +1402,9 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
   ProfScope ps;
   prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
   const bool packed = vec && Cin == Cout && (Cin == 16 || Cin == 32) && perm == nullptr;
-  const dim3 pgrid(ceil_div((long long)KV * S * 64, 256)), wgrid(ceil_div(waves * 64, 256));
+  const int S4 = (S + 3) / 4;  // the vector kernels sum 4 row splits per workgroup through LDS
+  const dim3 pgrid((unsigned)((long long)KV * S4)), wgrid((unsigned)((long long)KV * S4 * GI * GJ));
+  int slabs = S4;
   if (packed && Cin == 16) {
     if (io_bf16) hipLaunchKernelGGL((spconv_wgrad_packed_kernel<4, true>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
     else hipLaunchKernelGGL((spconv_wgrad_packed_kernel<4, false>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
@@ -1398,12 +1415,13 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
     if (io_bf16) hipLaunchKernelGGL(spconv_wgrad64_kernel<true>, wgrid, dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
     else hipLaunchKernelGGL(spconv_wgrad64_kernel<false>, wgrid, dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
   } else {
-    hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), wgrid, dim3(256), 0, stream, (const float *)in, Cin, (const float *)dout, Cout,
+    slabs = S;
+    hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, (const float *)in, Cin, (const float *)dout, Cout,
                        pairs, ld, KV, n_rows, S, GI, GJ, partial);
   }
   prof_end(&ps);  // the events bracket the dominant kernel only, so their average matches rocprof's for that kernel
   long long total = (long long)KV * Cin * Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, partial, S, KV, Cin, Cout, dW);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, partial, slabs, KV, Cin, Cout, dW);
   return check_launch("spconv_wgrad");
 }
 
