@@ -124,11 +124,13 @@ __device__ __forceinline__ bool out_coord(const ConvGeom &G, int4 c, int k, int 
   return ox < G.out0 && oy < G.out1 && oz < G.out2;
 }
 
+// n_dev (optional): the true number of input rows lives on the device (N is then the host-side bound of the launch)
 __global__ __launch_bounds__(256) void sparse_mark_kernel(const int4 *__restrict__ indices, int N,
-                                                          ConvGeom G, unsigned *__restrict__ bitmap) {
+                                                          const int *__restrict__ n_dev, ConvGeom G,
+                                                          unsigned *__restrict__ bitmap) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  if (n >= N) return;
+  if (n >= N || (n_dev && n >= *n_dev)) return;
   int ox, oy, oz;
   int4 c = indices[n];
   if (!out_coord(G, c, k, ox, oy, oz)) return;
@@ -1176,10 +1178,10 @@ BFHIP_EXPORT size_t bfhip_rulebook_sparse_workspace_bytes(int B, const int *in_s
   return 2 * align_up((size_t)nwords * sizeof(int), 256) + align_up((nb + 1) * sizeof(int), 256) + 256;
 }
 
-BFHIP_EXPORT int bfhip_rulebook_sparse_count(const int32_t *indices, int N, int B, const int *in_shape,
-                                             const int *ksize, const int *stride, const int *padding,
-                                             const int *dilation, int32_t *counts_dev, void *workspace,
-                                             size_t workspace_bytes, void *stream_) {
+BFHIP_EXPORT int bfhip_rulebook_sparse_count(const int32_t *indices, int N, const int32_t *n_in_dev, int B,
+                                             const int *in_shape, const int *ksize, const int *stride,
+                                             const int *padding, const int *dilation, int32_t *counts_dev,
+                                             void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ConvGeom G;
   BFHIP_REQUIRE(N >= 0, "rulebook_sparse: N < 0");
@@ -1199,13 +1201,39 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_count(const int32_t *indices, int N, int 
   hipMemsetAsync(bitmap, 0, nwords * sizeof(unsigned), stream);
   hipMemsetAsync(counts_dev, 0, 65 * sizeof(int), stream);
   if (N > 0) {
-    hipLaunchKernelGGL(sparse_mark_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, G, bitmap);
+    hipLaunchKernelGGL(sparse_mark_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, n_in_dev, G, bitmap);
   }
   hipLaunchKernelGGL(words_count_kernel, dim3(nb), dim3(kScan), 0, stream, bitmap, nwords, blk);
   hipLaunchKernelGGL(blocks_scan_kernel, dim3(1), dim3(kScan), 0, stream, blk, nb, counts_dev);
   hipLaunchKernelGGL(words_prefix_kernel, dim3(nb), dim3(kScan), 0, stream, bitmap, nwords, blk, word_prefix);
   prof_end(&ps);
   return check_launch("rulebook_sparse_count");
+}
+
+// Output coordinates of a counted layer into a buffer of `cap` rows, without knowing N_out on the host (rows beyond cap are
+// dropped; the caller compares counts_dev[0] with cap after its single read).  Lets a chain of strided layers be counted
+// back to back: the next layer's bfhip_rulebook_sparse_count takes this buffer with n_in_dev = counts_dev of this one.
+BFHIP_EXPORT int bfhip_rulebook_sparse_out_indices(int B, const int *in_shape, const int *ksize, const int *stride,
+                                                   const int *padding, const int *dilation, int cap,
+                                                   int32_t *out_indices, void *workspace, size_t workspace_bytes,
+                                                   void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvGeom G;
+  BFHIP_REQUIRE(make_geom(B, in_shape, ksize, stride, padding, dilation, false, G) == 0, "rulebook_sparse_out_indices: bad geometry");
+  BFHIP_REQUIRE(cap > 0 && out_indices && ((uintptr_t)out_indices % 16) == 0, "rulebook_sparse_out_indices: bad output buffer");
+  size_t need = bfhip_rulebook_sparse_workspace_bytes(B, in_shape, ksize, stride, padding, dilation);
+  if (workspace_bytes < need || !workspace) { set_error("rulebook_sparse_out_indices: workspace too small"); return BFHIP_E_WORKSPACE; }
+  long long cells = (long long)B * G.out0 * G.out1 * G.out2;
+  long long nwords = (cells + 31) / 32;
+  Workspace ws(workspace, workspace_bytes);
+  unsigned *bitmap = ws.take<unsigned>(nwords);
+  int *word_prefix = ws.take<int>(nwords);
+  ProfScope ps;
+  prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
+  hipLaunchKernelGGL(sparse_out_indices_kernel, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream, bitmap, word_prefix,
+                     nwords, G, cap, (int4 *)out_indices);
+  prof_end(&ps);
+  return check_launch("rulebook_sparse_out_indices");
 }
 
 BFHIP_EXPORT int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *in_shape,

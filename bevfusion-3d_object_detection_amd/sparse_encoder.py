@@ -3,6 +3,7 @@ its layer factory `make_encoder_layers` (mmdet3d/models/middle_encoders/sparse_e
 `SparseBasicBlock` and `make_sparse_convmodule` (mmdet3d/models/layers/sparse_block.py:94-224).
 Conv arithmetic: csrc/spconv.hip via spconv.py; BatchNorm1d / ReLU on the [N, C] feature matrix are torch.
 """
+import os
 from typing import Optional, Tuple, Union
 
 import torch
@@ -10,7 +11,7 @@ from torch import nn
 
 from .registry import MODELS
 from .spconv import (BatchNorm1dAct, SparseConv3d, SparseConvTensor, SparseModule, SparseSequential,  # noqa: F401
-                     SubMConv3d, replace_feature)
+                     SubMConv3d, prepare_strided_rulebooks, replace_feature)
 
 _CONV_TYPES = {"SubMConv3d": SubMConv3d, "SparseConv3d": SparseConv3d}
 
@@ -98,6 +99,9 @@ class BEVFusionSparseEncoder(nn.Module):
         # False: NCHW-contiguous fp32 output like the reference; True: the same tensor with channels-last strides (in the
         # autocast dtype when autocast is on) so the NHWC convs of the fuser / BEV backbone take it without a copy
         self.bev_channels_last = False
+        # count the outputs of all strided layers up front: one host read per forward (BFHIP_PRESIZE_RULEBOOKS=0: one per layer)
+        self.presize_rulebooks = os.environ.get("BFHIP_PRESIZE_RULEBOOKS", "1") == "1"
+        self._nout_hints = []  # N_out of the strided layers in the previous forward: sizes the capped buffers of the next one
         first_order = ("conv",) if order[0] != "conv" else order  # pre-activation variant keeps a bare first conv
         self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
                                                  indice_key="subm1", conv_type="SubMConv3d", order=first_order)
@@ -138,6 +142,12 @@ class BEVFusionSparseEncoder(nn.Module):
     def forward(self, voxel_features, coors, batch_size):
         coors = coors.int()
         x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        if self.presize_rulebooks and coors.is_cuda:
+            # all strided layers' output counts in ONE host read (instead of one per layer)
+            chain = [m for m in self.modules() if isinstance(m, SparseConv3d)]  # registration order = execution order
+            x.indice_dict["_strided_plans"] = prepare_strided_rulebooks(
+                coors, batch_size, self.sparse_shape, [(m.kernel_size, m.stride, m.padding, m.dilation) for m in chain],
+                hints=self._nout_hints)
         x = self.conv_input(x)
         encode_features = []
         for encoder_layer in self.encoder_layers:

@@ -94,24 +94,89 @@ def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
     return [(spatial_shape[i] + 2 * padding[i] - dilation[i] * (ksize[i] - 1) - 1) // stride[i] + 1 for i in range(3)]
 
 
-def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation):
+class StridedPlan:
+    """What `prepare_strided_rulebooks` leaves for one strided layer: its geometry, N_out (host int) and the workspace
+    holding the counted bitmap / prefix sums that `bfhip_rulebook_sparse_fill` needs."""
+
+    def __init__(self, geo_key, n_out, counts, ws):
+        self.geo_key, self.n_out, self.counts, self.ws = geo_key, n_out, counts, ws
+
+
+def _geo_key(spatial_shape, ksize, stride, padding, dilation):
+    return (tuple(spatial_shape), tuple(ksize), tuple(stride), tuple(padding), tuple(dilation))
+
+
+def prepare_strided_rulebooks(indices, batch_size, spatial_shape, specs, hints=None):
+    """Count the outputs of a CHAIN of strided sparse convs (specs: [(ksize, stride, padding, dilation), ...], each applied to
+    the previous one's output coordinates; SubM layers in between do not change coordinates) with ONE host read for all of
+    them instead of one per layer.  Output coordinates of a level go into a capped buffer whose true length
+    stays on the device and feeds the next level's count.  Returns {geometry key: StridedPlan}; a level whose N_out
+    exceeded its cap (and everything after it) is left out and takes the per-layer path.  `hints` (the N_out values of the
+    previous forward, if any) tighten the caps to 1.5x: consecutive frames have similar occupancy, and the launches of the
+    following level are sized by the cap."""
+    dev = indices.device
+    lib = _lib.load()
+    stream = _lib.stream_of(indices)
+    N0 = indices.shape[0]
+    cur_idx, cur_cap, cur_n_dev, shape = indices, N0, None, list(spatial_shape)
+    levels = []
+    if N0 == 0:
+        return {}
+    with torch.cuda.device(dev):
+        for ksize, stride, padding, dilation in specs:
+            geo = [_lib.host_i32(shape), _lib.host_i32(ksize), _lib.host_i32(stride), _lib.host_i32(padding),
+                   _lib.host_i32(dilation)]
+            nbytes = lib.bfhip_rulebook_sparse_workspace_bytes(batch_size, *geo)
+            if nbytes == 0:
+                break
+            out_shape = conv_out_shape(shape, ksize, stride, padding, dilation)
+            cells = batch_size * out_shape[0] * out_shape[1] * out_shape[2]
+            cap = int(min(cells, 8 * cur_cap, max(4 * N0, 1 << 16)))
+            if hints is not None and len(levels) < len(hints) and hints[len(levels)] > 0:
+                cap = int(min(cap, hints[len(levels)] * 3 // 2 + 4096))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)  # kept until the layer's fill
+            counts = torch.zeros(65, dtype=torch.int32, device=dev)
+            _lib.check(lib.bfhip_rulebook_sparse_count(_lib.ptr(cur_idx), cur_cap, _lib.ptr(cur_n_dev), batch_size, *geo,
+                                                       _lib.ptr(counts), _lib.ptr(ws), ws.numel(), stream), "rulebook_sparse_count")
+            tmp_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+            _lib.check(lib.bfhip_rulebook_sparse_out_indices(batch_size, *geo, cap, _lib.ptr(tmp_idx), _lib.ptr(ws), ws.numel(),
+                                                             stream), "rulebook_sparse_out_indices")
+            levels.append((_geo_key(shape, ksize, stride, padding, dilation), counts, ws, cap))
+            cur_idx, cur_cap, cur_n_dev, shape = tmp_idx, cap, counts[0:1], out_shape
+    if not levels:
+        return {}
+    n_outs = torch.stack([c[0] for _, c, _, _ in levels]).tolist()  # the one host read
+    if hints is not None:
+        hints[:] = n_outs
+    plans = {}
+    for (key, counts, ws, cap), n_out in zip(levels, n_outs):
+        if n_out > cap:
+            break  # this level (and its successors, counted from a truncated input) falls back to the per-layer path
+        plans[key] = StridedPlan(key, int(n_out), counts, ws)
+    return plans
+
+
+def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, plan=None):
     N = indices.shape[0]
     kv = ksize[0] * ksize[1] * ksize[2]
     dev = indices.device
     lib = _lib.load()
     geo = [_lib.host_i32(spatial_shape), _lib.host_i32(ksize), _lib.host_i32(stride), _lib.host_i32(padding),
            _lib.host_i32(dilation)]
-    nbytes = lib.bfhip_rulebook_sparse_workspace_bytes(batch_size, *geo)
-    if nbytes == 0:
-        raise RuntimeError("SparseConv3d: unsupported geometry")
-    ws = _workspace(dev, nbytes, "rule")
-    counts = torch.zeros(65, dtype=torch.int32, device=dev)  # [N_out, 64 spread pair counters]
     stream = _lib.stream_of(indices)
     with torch.cuda.device(dev):
-        rc = lib.bfhip_rulebook_sparse_count(_lib.ptr(indices), N, batch_size, *geo, _lib.ptr(counts), _lib.ptr(ws),
-                                             ws.numel(), stream)
-        _lib.check(rc, "rulebook_sparse_count")
-        n_out = int(counts[0].item())  # the one host sync of a strided layer (spconv returns num_act_out too)
+        if plan is not None:
+            ws, counts, n_out = plan.ws, plan.counts, plan.n_out  # counted by prepare_strided_rulebooks: no host read here
+        else:
+            nbytes = lib.bfhip_rulebook_sparse_workspace_bytes(batch_size, *geo)
+            if nbytes == 0:
+                raise RuntimeError("SparseConv3d: unsupported geometry")
+            ws = _workspace(dev, nbytes, "rule")
+            counts = torch.zeros(65, dtype=torch.int32, device=dev)  # [N_out, 64 spread pair counters]
+            rc = lib.bfhip_rulebook_sparse_count(_lib.ptr(indices), N, None, batch_size, *geo, _lib.ptr(counts), _lib.ptr(ws),
+                                                 ws.numel(), stream)
+            _lib.check(rc, "rulebook_sparse_count")
+            n_out = int(counts[0].item())  # the one host sync of a strided layer (spconv returns num_act_out too)
         out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
         pair_fwd = torch.empty((kv, n_out), dtype=torch.int32, device=dev)
         pair_bwd = torch.empty((kv, N), dtype=torch.int32, device=dev)
@@ -524,8 +589,10 @@ class SparseConvolution(SparseModule):
                                            self.dilation)
                 input._auto_rulebooks[auto_key] = data
         else:
+            plans = input.indice_dict.get("_strided_plans") or {}
+            plan = plans.get(_geo_key(input.spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation))
             data = build_sparse_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size,
-                                         self.stride, self.padding, self.dilation)
+                                         self.stride, self.padding, self.dilation, plan=plan)
         if self.indice_key is not None:
             input.indice_dict[self.indice_key] = data
         return data

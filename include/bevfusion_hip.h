@@ -211,10 +211,15 @@ int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const int *in_shap
 size_t bfhip_rulebook_sparse_workspace_bytes(int B, const int *in_shape, const int *ksize,
                                              const int *stride, const int *padding,
                                              const int *dilation);
-int bfhip_rulebook_sparse_count(const int32_t *indices, int N, int B, const int *in_shape,
-                                const int *ksize, const int *stride, const int *padding,
-                                const int *dilation, int32_t *counts_dev, void *workspace,
-                                size_t workspace_bytes, void *stream);
+/* n_in_dev (optional): the true number of input rows on the device; N is then only the launch bound.  With
+ * bfhip_rulebook_sparse_out_indices (output coordinates into a buffer of `cap` rows, no host-side N_out) a chain of strided
+ * layers is counted back to back and all N_out values are read in ONE host read. */
+int bfhip_rulebook_sparse_count(const int32_t *indices, int N, const int32_t *n_in_dev, int B, const int *in_shape,
+                                const int *ksize, const int *stride, const int *padding, const int *dilation,
+                                int32_t *counts_dev, void *workspace, size_t workspace_bytes, void *stream);
+int bfhip_rulebook_sparse_out_indices(int B, const int *in_shape, const int *ksize, const int *stride,
+                                      const int *padding, const int *dilation, int cap, int32_t *out_indices,
+                                      void *workspace, size_t workspace_bytes, void *stream);
 int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *in_shape,
                                const int *ksize, const int *stride, const int *padding,
                                const int *dilation, int n_out, int32_t *out_indices,

@@ -322,3 +322,31 @@ def test_to_bev_channels_last_matches_nchw(dev):
     f1.grad = None
     h.backward(wide[:, 8:].to(torch.bfloat16))
     assert torch.allclose(f1.grad, f0.grad, rtol=1e-2, atol=1e-2)
+
+
+def test_presized_strided_rulebooks_are_identical(dev):
+    """Counting all strided layers up front (one host read) yields the same rulebooks and the same BEV map, bit
+    for bit, as the per-layer path; a level that overflows its cap falls back to the per-layer path."""
+    from bevfusion_amd import spconv as sp
+    from bevfusion_amd.sparse_encoder import BEVFusionSparseEncoder
+    B, shape, n = 2, (96, 96, 41), 6000
+    idx, feats = random_sparse(B, shape, n, 5, seed=21)
+    torch.manual_seed(0)
+    enc = BEVFusionSparseEncoder(in_channels=5, sparse_shape=list(shape), norm_cfg=dict(type="BN1d", eps=0.001, momentum=0.01),
+                                 encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                                 encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, (1, 1, 0)), (0, 0)), block_type="basicblock",
+                                 return_middle_feats=True).to(dev).eval()
+    f, c = torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev)
+    with torch.no_grad():
+        enc.presize_rulebooks = True
+        bev1, mid1 = enc(f, c, B)
+        enc.presize_rulebooks = False
+        bev0, mid0 = enc(f, c, B)
+    assert torch.equal(bev0, bev1)
+    for a, b in zip(mid0, mid1):
+        assert torch.equal(a.indices, b.indices) and torch.equal(a.features, b.features)
+    # the plan itself: 4 strided levels, N_out equal to what each layer produced
+    specs = [(m.kernel_size, m.stride, m.padding, m.dilation) for m in enc.modules() if isinstance(m, sp.SparseConv3d)]
+    plans = sp.prepare_strided_rulebooks(c, B, list(shape), specs)
+    assert len(plans) == 4
+    assert sorted(p.n_out for p in plans.values()) == sorted([m.indices.shape[0] for m in mid0[:3]] + [int((bev0.abs().sum(1) > 0).sum() * 0 + sp.build_sparse_rulebook(mid0[3].indices, B, mid0[3].spatial_shape, *specs[3]).out_indices.shape[0])])
