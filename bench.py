@@ -489,7 +489,8 @@ def main():
             else:
                 ach = w["flops"] / sec_per_step / 1e12
                 roof = {"bound": "mfma", "kernel": dom + " (all sparse conv layers of the step)", "achieved": round(ach, 2),
-                        "peak": w["unit_peak"], "unit": "TFLOP/s", "frac": round(ach / w["unit_peak"], 4), "traffic": None,
+                        "peak": w["unit_peak"], "unit": "TFLOP/s", "frac": round(ach / w["unit_peak"], 4),
+                        "traffic": int(pmc[dom]["hbm_bytes"]) if (dom in pmc and args.batch == 4 and args.workload == "full") else None,
                         "algorithmic_flops_per_step": w["flops"], "algorithmic_bytes_per_step": int(w["bytes"]),
                         "ms_per_step": round(ms / args.steps, 5), "launches_per_step": cnt / args.steps,
                         "note": "peaks from MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s, bf16 MFMA ~2500 TFLOP/s dense"}
