@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
     ap.add_argument("--workload", default="full", choices=["full", "lidar_only", "lidar_branch", "camera_only", "hotpath_v1", "dist_selftest"])
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --workload dist_selftest (CPU)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: --workload dist_selftest (CPU), or a one-GPU rehearsal of the multi-rank path with BENCH_ONE_GPU=1")
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2, help="bounded CPU sample (frames)")
@@ -400,6 +400,11 @@ def main():
     os.dup2(2, 1)
     if not cpu_mode and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # BENCH_ONE_GPU=1 (with --backend gloo): every rank uses cuda:0 and gradients are reduced through gloo -- a rehearsal of the
+    # multi-rank code path (rank-dependent inputs, DDP buckets incl. the bf16 ones, max-over-ranks timing) on a one-GPU box
+    one_gpu = os.environ.get("BENCH_ONE_GPU", "0") == "1" and args.backend == "gloo"
+    if one_gpu:
+        local_rank = 0
     if cpu_mode:
         dev = torch.device("cpu")
     else:
@@ -412,7 +417,7 @@ def main():
         if force_ddp and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"), RANK="0",
                               WORLD_SIZE="1", LOCAL_RANK="0")
-        if cpu_mode:
+        if cpu_mode or one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
