@@ -79,3 +79,21 @@ def test_decoder_layer_uses_split_attention_under_autocast(dev):
         finally:
             at.ENABLED = True
     assert rel(out.float(), ref.float()) < 2e-2
+
+
+def test_cross_attention_edge_sizes(dev):
+    """One query, a key count that is not a multiple of the 512-key chunk, and the smallest supported key count."""
+    torch.manual_seed(3)
+    for B, H, Lq, Lk in ((1, 1, 1, 2048), (2, 3, 5, 2500), (1, 8, 256, 3001)):
+        E = H * 16
+        q = torch.randn(B, Lq, E, device=dev).to(torch.bfloat16).requires_grad_(True)
+        k = torch.randn(B, Lk, E, device=dev).to(torch.bfloat16).requires_grad_(True)
+        v = torch.randn(B, Lk, E, device=dev).to(torch.bfloat16).requires_grad_(True)
+        out = at.cross_attention(q, k, v, H, 0.0)
+        qr, kr, vr = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+        ref = reference(qr, kr, vr, H)
+        assert rel(out.float(), ref) < 2e-2, (B, H, Lq, Lk)
+        out.float().sum().backward()
+        ref.sum().backward()
+        assert rel(v.grad.float(), vr.grad) < 3e-2 and rel(q.grad.float(), qr.grad) < 5e-2
+    assert not at.supported(torch.zeros(1, 300, 128, device=dev, dtype=torch.bfloat16), k[:1, :, :128].expand(1, -1, 128), k[:1, :, :128].expand(1, -1, 128), 8)

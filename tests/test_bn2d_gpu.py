@@ -143,3 +143,20 @@ def test_upsample2x_matches_interpolate(dev, dtype, tol, shape):
     assert rel(x.grad.float(), xr.grad) < tol
     # non-2x sizes take the torch path
     assert upsample_to(x.detach(), (size[0] + 1, size[1]), cfg).shape[2] == size[0] + 1
+
+
+def test_bn2d_tiny_and_odd_sizes(dev):
+    """M smaller than one slab, M not a multiple of the row lanes, a single spatial position."""
+    torch.manual_seed(5)
+    for shape in ((2, 16, 1, 1), (1, 64, 3, 1), (7, 8, 2, 3), (2, 1024, 1, 2)):
+        x = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        bn = bn2d.BatchNorm2dAct(shape[1], act=True).to(dev).train()
+        assert bn.fusable(x)
+        y = bn(x)
+        xr = x.detach().clone().requires_grad_(True)
+        yr = F.relu(F.batch_norm(xr, None, None, bn.weight, bn.bias, True, 0.1, bn.eps))
+        assert torch.allclose(y, yr, atol=2e-5, rtol=1e-4), shape
+        g = torch.randn_like(y)
+        y.backward(g)
+        yr.backward(g)
+        assert rel(x.grad, xr.grad) < 1e-3 or float(xr.grad.abs().max()) < 1e-6, shape

@@ -70,3 +70,16 @@ def test_spelled_out_mha_equals_nn_multiheadattention(dev):
     out2 = q + m.attn(q + qp, k + kp, k + kp, need_weights=False)[0]
     rw = torch.autograd.grad(out2.square().sum(), m.attn.in_proj_weight)[0]
     assert rel(gw, rw) < 1e-3
+
+
+def test_xty_edge_sizes(dev):
+    for K, M, N in ((1, 4, 4), (3, 1, 1), (65, 130, 3), (17, 64, 64)):
+        x = torch.randn(K, M, device=dev)
+        y = torch.randn(K, N, device=dev)
+        ref = x.double().t() @ y.double()
+        assert rel(lr.xty(x, y), ref) < 2e-5, (K, M, N)
+    # a zero-row gradient is a zero matrix through the public wrapper (plain F.linear path below MIN_ROWS)
+    w = torch.randn(8, 4, device=dev, requires_grad=True)
+    out = lr.linear_rows(torch.zeros(0, 4, device=dev), w)
+    out.sum().backward()
+    assert out.shape == (0, 8) and float(w.grad.abs().sum()) == 0.0
