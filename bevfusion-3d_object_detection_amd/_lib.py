@@ -82,6 +82,8 @@ SIGNATURES = {
     "bfhip_attn_dropout_mask": (_c_int, [_c_int] * 4 + [ctypes.c_float, ctypes.c_ulonglong, _c_vp, _c_vp]),
     "bfhip_upsample2x_nhwc": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp]),
     "bfhip_circle_nms": (_c_int, [_c_vp, _c_int, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp]),
+    "bfhip_rotate_nms_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "bfhip_rotate_nms": (_c_int, [_c_vp, _c_vp, _c_int, ctypes.c_float, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_decode_boxes": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp, _c_vp, _c_vp]),
     "bfhip_assign_cost": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 +
                           [_c_vp] * 4),

@@ -497,6 +497,78 @@ __global__ __launch_bounds__(256) void circle_nms_kernel(const float *__restrict
   if (threadIdx.x == 0) *n_keep = kept < post_max ? kept : post_max;
 }
 
+// ---------------------------------------------------------------------------------------- rotate NMS
+// nms_bev (mmdet3d/models/layers/box3d_nms.py:234-275) -> mmcv.ops.nms_rotated (third-party, mmcv 2.x; restated from its
+// published algorithm): sort by score, keep the first pre_max, IoU of rotated rectangles (x, y, w, h, angle) on the
+// exact intersection polygon, a box is suppressed by an earlier kept box when IoU > thresh.  Three launches:
+//   rank+stage (one thread per box)  ->  suppression bit matrix (one thread per (row, 64-column word))  ->  serial sweep (one wave).
+__global__ __launch_bounds__(256) void rnms_rank_kernel(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                                        int n, int m, int *__restrict__ order, float *__restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float si = scores[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float sj = scores[j];
+      rank += (sj > si) || (sj == si && j < i);
+    }
+    if (rank < m) {
+      order[rank] = i;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) sorted[rank * 5 + c] = boxes[i * 5 + c];
+    }
+  }
+}
+
+__device__ __forceinline__ float iou_rotated(const float *a, const float *b) {
+  const float ar1 = a[2] * a[3], ar2 = b[2] * b[3];
+  if (ar1 < 1e-14f || ar2 < 1e-14f) return 0.f;
+  const float inter = rotated_intersection(a[0], a[1], a[2], a[3], a[4], b[0], b[1], b[2], b[3], b[4]);
+  return inter / (ar1 + ar2 - inter);
+}
+
+// mask[i][w] bit b: sorted box j = 64 w + b (j > i) overlaps sorted box i by more than thresh
+__global__ __launch_bounds__(64) void rnms_mask_kernel(const float *__restrict__ sorted, int m, int words, float thresh,
+                                                       unsigned long long *__restrict__ mask) {
+  __shared__ float cols[64 * 5];
+  const int w = blockIdx.x, i = blockIdx.y * 64 + threadIdx.x;
+  if (w * 64 + 63 <= (int)blockIdx.y * 64) {  // whole word at or left of the diagonal for every row of this block
+    if (i < m) mask[(size_t)i * words + w] = 0ull;
+    return;
+  }
+  const int ncol = min(64, m - w * 64);
+  for (int t = threadIdx.x; t < ncol * 5; t += 64) cols[t] = sorted[(size_t)w * 64 * 5 + t];
+  __syncthreads();
+  if (i >= m) return;
+  float a[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) a[c] = sorted[(size_t)i * 5 + c];
+  unsigned long long bits = 0ull;
+  for (int b = 0; b < ncol; ++b) {
+    const int j = w * 64 + b;
+    if (j <= i) continue;
+    if (iou_rotated(a, cols + b * 5) > thresh) bits |= 1ull << b;
+  }
+  mask[(size_t)i * words + w] = bits;
+}
+
+// one wave: lane l owns removed-word l (+64, ... for m > 4096 is excluded by the host check)
+__global__ __launch_bounds__(64) void rnms_sweep_kernel(const unsigned long long *__restrict__ mask,
+                                                        const int *__restrict__ order, int m, int words, int post_max,
+                                                        int *__restrict__ keep, int *__restrict__ n_keep) {
+  const int lane = threadIdx.x;
+  unsigned long long removed = 0ull;
+  int kept = 0;
+  for (int i = 0; i < m; ++i) {
+    const unsigned long long wi = __shfl(removed, i >> 6);
+    if ((wi >> (i & 63)) & 1ull) continue;  // wave-uniform
+    if (lane == 0 && kept < post_max) keep[kept] = order[i];
+    ++kept;
+    if (lane < words) removed |= mask[(size_t)i * words + lane];
+  }
+  if (lane == 0) *n_keep = kept < post_max ? kept : post_max;
+}
+
 }  // namespace
 }  // namespace bfhip
 
@@ -512,6 +584,35 @@ BFHIP_EXPORT int bfhip_circle_nms(const float *dets, int n, float thresh, int po
   hipLaunchKernelGGL(circle_nms_kernel, dim3(1), dim3(256), (size_t)n * 16, (hipStream_t)stream, dets, n, thresh, post_max_size,
                      keep, n_keep);
   return check_launch("circle_nms");
+}
+
+BFHIP_EXPORT size_t bfhip_rotate_nms_workspace_bytes(int n, int pre_max_size) {
+  const size_t m = (size_t)(n < pre_max_size ? n : pre_max_size), words = (m + 63) / 64;
+  return align_up(m * sizeof(int32_t), 256) + align_up(m * 5 * sizeof(float), 256) + align_up(m * words * 8, 256);
+}
+
+BFHIP_EXPORT int bfhip_rotate_nms(const float *boxes, const float *scores, int n, float thresh, int pre_max_size,
+                                  int post_max_size, int32_t *keep, int32_t *n_keep, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  BFHIP_REQUIRE(n_keep && n >= 0 && pre_max_size >= 0 && post_max_size >= 0, "rotate_nms: bad arguments");
+  const int m = n < pre_max_size ? n : pre_max_size;
+  hipStream_t s = (hipStream_t)stream;
+  if (m == 0) {
+    if (hipMemsetAsync(n_keep, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("rotate_nms memset");
+    return BFHIP_OK;
+  }
+  BFHIP_REQUIRE(boxes && scores && keep && workspace, "rotate_nms: null pointer");
+  BFHIP_REQUIRE(n <= 16384 && m <= 4096, "rotate_nms: n=%d (<= 16384), min(n, pre_max_size)=%d (<= 4096)", n, m);
+  BFHIP_REQUIRE(workspace_bytes >= bfhip_rotate_nms_workspace_bytes(n, pre_max_size), "rotate_nms: workspace too small");
+  const int words = (m + 63) / 64;
+  char *w = (char *)workspace;
+  int *order = (int *)w;                w += align_up((size_t)m * sizeof(int32_t), 256);
+  float *sorted = (float *)w;           w += align_up((size_t)m * 5 * sizeof(float), 256);
+  unsigned long long *mask = (unsigned long long *)w;
+  hipLaunchKernelGGL(rnms_rank_kernel, dim3((n + 255) / 256), dim3(256), 0, s, boxes, scores, n, m, order, sorted);
+  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, words), dim3(64), 0, s, sorted, m, words, thresh, mask);
+  hipLaunchKernelGGL(rnms_sweep_kernel, dim3(1), dim3(64), 0, s, mask, order, m, words, post_max_size, keep, n_keep);
+  return check_launch("rotate_nms");
 }
 
 BFHIP_EXPORT int bfhip_decode_boxes(const float *center, const float *height, const float *dim, const float *rot,

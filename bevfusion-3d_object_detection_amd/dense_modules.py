@@ -490,11 +490,10 @@ class BEVFusionHead(nn.Module):
         score = score * preds["query_heatmap_score"] * one_hot
         vel = preds["vel"][..., -P:] if "vel" in preds else None
         nms_type = (self.test_cfg or {}).get("nms_type", None)
-        assert nms_type in (None, "circle"), "nms_type None (the reference's nuScenes setting) and 'circle' are implemented"
         rets = self.bbox_coder.decode(score, preds["rot"][..., -P:], preds["dim"][..., -P:], preds["center"][..., -P:],
                                       preds["height"][..., -P:], vel, filter=True)
-        if nms_type == "circle":
-            from .head_targets import circle_nms
+        if nms_type is not None:
+            from .head_targets import circle_nms, nms_bev, xywhr2xyxyr
             # nuScenes tasks (:358-378): classes 0-7 untouched, pedestrians (8) and traffic cones (9) with radius 0.175
             tasks = [(list(range(8)), -1.0), ([8], 0.175), ([9], 0.175)] if (self.test_cfg or {}).get("dataset") == "nuScenes" \
                 else [([0], 0.7), ([1], 0.7), ([2], 0.7)]
@@ -508,7 +507,12 @@ class BEVFusionHead(nn.Module):
                         task_mask |= labels == c
                     if radius > 0:
                         idx = torch.where(task_mask)[0]
-                        kept = circle_nms(torch.cat([boxes[idx, :2], scores[idx, None]], dim=1), radius)
+                        if nms_type == "circle":
+                            kept = circle_nms(torch.cat([boxes[idx, :2], scores[idx, None]], dim=1), radius)
+                        else:  # any other value: rotated-IoU NMS with the task radius as the IoU threshold (:414-423)
+                            bev = boxes[idx][:, [0, 1, 3, 4, 6]]
+                            kept = nms_bev(xywhr2xyxyr(bev), scores[idx], radius, self.test_cfg.get("pre_max_size"),
+                                           self.test_cfg.get("post_max_size"))
                         keep_mask[idx[kept]] = True
                     else:
                         keep_mask |= task_mask

@@ -256,6 +256,39 @@ def circle_nms(dets, thresh, post_max_size=83):
     return keep[:int(count.item())].long()
 
 
+def rotate_nms(boxes_xywhr, scores, thresh, pre_max_size=None, post_max_size=None):
+    """mmcv.ops.nms_rotated behind nms_bev, on the device: boxes [N, 5] = (x, y, w, h, angle) -> kept indices (int64,
+    highest score first).  One host read (the number of kept boxes)."""
+    n = int(boxes_xywhr.shape[0])
+    b, sc = _f32c(boxes_xywhr), _f32c(scores)
+    pre = n if pre_max_size is None else int(pre_max_size)
+    post = n if post_max_size is None else int(post_max_size)
+    keep = torch.empty(max(min(n, pre, post), 1), dtype=torch.int32, device=b.device)
+    count = torch.empty(1, dtype=torch.int32, device=b.device)
+    wsb = _lib.call_size("bfhip_rotate_nms_workspace_bytes", n, pre)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=b.device)
+    _lib.call("bfhip_rotate_nms", _lib.ptr(b) if n else None, _lib.ptr(sc) if n else None, n, float(thresh), pre, post,
+              _lib.ptr(keep), _lib.ptr(count), _lib.ptr(ws), wsb, _lib.stream_of(b))
+    return keep[:int(count.item())].long()
+
+
+def xywhr2xyxyr(boxes_xywhr):
+    """mmdet3d/structures/bbox_3d/utils.py:128-147."""
+    half_w, half_h = boxes_xywhr[..., 2] / 2, boxes_xywhr[..., 3] / 2
+    return torch.stack([boxes_xywhr[..., 0] - half_w, boxes_xywhr[..., 1] - half_h, boxes_xywhr[..., 0] + half_w,
+                        boxes_xywhr[..., 1] + half_h, boxes_xywhr[..., 4]], dim=-1)
+
+
+def nms_bev(boxes, scores, thresh, pre_max_size=None, post_max_size=None):
+    """mmdet3d/models/layers/box3d_nms.py:234-275 with its argument convention: boxes [N, 5] = (x1, y1, x2, y2, ry).
+    The xyxyr -> xywhr conversion is the reference's fp32 arithmetic; sort, pre/post limits and suppression run in
+    bfhip_rotate_nms."""
+    assert boxes.shape[1] == 5, "Input boxes shape should be [N, 5]"
+    xywhr = torch.stack(((boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2, boxes[:, 2] - boxes[:, 0],
+                         boxes[:, 3] - boxes[:, 1], boxes[:, 4]), dim=-1)
+    return rotate_nms(xywhr, scores, thresh, pre_max_size, post_max_size)
+
+
 # ----------------------------------------------------------------------------------------------- targets
 def build_targets(assigned, iou, gt_boxes, gt_labels, num_classes, code_size, pc_range, out_size_factor, voxel_size,
                   pos_weight=-1):

@@ -403,6 +403,15 @@ int bfhip_gaussian_focal_loss(const float *logits, const float *target, long lon
  * n_keep i32[1].  n <= 4096. */
 int bfhip_circle_nms(const float *dets, int n, float thresh, int post_max_size, int32_t *keep, int32_t *n_keep,
                      void *stream);
+/* rotate NMS: nms_bev (mmdet3d/models/layers/box3d_nms.py:234-275) -> mmcv.ops.nms_rotated, called from
+ * BEVFusionHead.predict_by_feat :414-423 when test_cfg.nms_type is neither None nor 'circle'.
+ * boxes f32[n,5] = (x, y, w, h, angle), scores f32[n]; the min(n, pre_max_size) highest-scoring boxes take part, box j is
+ * dropped when an earlier kept box overlaps it with IoU > thresh; keep i32[min(n, pre_max_size, post_max_size)] receives
+ * the kept indices (into boxes), highest score first; n_keep i32[1].  Equal scores: lower index first.
+ * n <= 16384, min(n, pre_max_size) <= 4096. */
+size_t bfhip_rotate_nms_workspace_bytes(int n, int pre_max_size);
+int bfhip_rotate_nms(const float *boxes, const float *scores, int n, float thresh, int pre_max_size, int post_max_size,
+                     int32_t *keep, int32_t *n_keep, void *workspace, size_t workspace_bytes, void *stream);
 int bfhip_query_losses(const float *cls_logits, const int32_t *labels, const float *label_weights,
                        const float *box_pred, const float *bbox_targets, const float *bbox_weights,
                        const float *code_weights, int B, int C, int P, int K, int ld, int p_off, float gamma,

@@ -337,6 +337,38 @@ def circle_nms(dets, thresh, post_max_size=83):
     return keep[:post_max_size] if post_max_size < len(keep) else keep
 
 
+def nms_rotated(boxes_xywhr, scores, thresh, pre_max_size=None, post_max_size=None):
+    """nms_bev (mmdet3d/models/layers/box3d_nms.py:234-275) around mmcv.ops.nms_rotated (third-party; its published
+    algorithm: descending score order, box j dropped when an earlier kept box has IoU(i, j) > thresh, IoU on the exact
+    intersection polygon of the rotated rectangles, 0 when either area < 1e-14).  Equal scores: lower index first.
+    Returns (kept indices into the input, IoU matrix of the sorted boxes)."""
+    b = np.asarray(boxes_xywhr, np.float64).reshape(-1, 5)
+    sc = np.asarray(scores, np.float32)
+    order = np.lexsort((np.arange(len(sc)), -sc))
+    if pre_max_size is not None:
+        order = order[:pre_max_size]
+    bs = b[order]
+    m = len(bs)
+    iou = np.zeros((m, m))
+    for i in range(m):
+        for j in range(i + 1, m):
+            a1, a2 = bs[i, 2] * bs[i, 3], bs[j, 2] * bs[j, 3]
+            if a1 < 1e-14 or a2 < 1e-14:
+                continue
+            inter = rotated_intersection_area(bs[i], bs[j])
+            iou[i, j] = inter / (a1 + a2 - inter)
+    removed = np.zeros(m, bool)
+    keep = []
+    for i in range(m):
+        if removed[i]:
+            continue
+        keep.append(int(order[i]))
+        removed |= iou[i] > thresh
+    if post_max_size is not None:
+        keep = keep[:post_max_size]
+    return keep, iou
+
+
 def heuristic_assign(bboxes, gt_bboxes, gt_labels=None, query_labels=None, dist_thre=100.0):
     """BF/utils.py:161-223 (HeuristicAssigner3D.assign) without the IoU of the matched pairs.
     Returns assigned_gt_inds [P] (0 = background, g+1), assigned labels [P] (-1 = none)."""

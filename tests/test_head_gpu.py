@@ -261,6 +261,58 @@ def test_circle_nms_matches_oracle(dev):
         assert len(ho.circle_nms(dets, 2.0, 83)) < 700 and len(ht.circle_nms(torch.from_numpy(dets).to(dev), 1e-9, 83)) == 83
 
 
+def _nms_boxes(rs, n):
+    centres = rs.uniform(-20, 20, (max(n // 5, 1), 2))
+    xy = centres[rs.randint(0, len(centres), n)] + rs.normal(0, 0.8, (n, 2))
+    wh = rs.uniform(0.5, 4.5, (n, 2))
+    ang = rs.uniform(-np.pi, np.pi, (n, 1))
+    return np.concatenate([xy, wh, ang], 1).astype(np.float32), rs.uniform(0, 1, n).astype(np.float32)
+
+
+def test_rotate_nms_matches_oracle(dev):
+    """bfhip_rotate_nms (fp32 polygon intersection) against the fp64 restatement of nms_bev / mmcv nms_rotated: the kept
+    index lists are identical whenever no pair's IoU lies within 1e-4 of the threshold (asserted for these seeds)."""
+    rs = np.random.RandomState(11)
+    for n, thresh, pre, post in ((0, 0.2, 1000, 83), (1, 0.2, 1000, 83), (64, 0.2, 1000, 83), (65, 0.1, 1000, 83),
+                                 (200, 0.2, 1000, 83), (300, 0.05, 130, 40), (500, 0.3, None, None)):
+        boxes, scores = _nms_boxes(rs, n) if n else (np.zeros((0, 5), np.float32), np.zeros(0, np.float32))
+        if n > 20:
+            scores[7] = scores[13]      # a score tie -> lower index first
+            boxes[3, 2] = 0.0           # a degenerate box: IoU 0 with everything, always kept
+            boxes[17] = boxes[16]       # identical boxes: IoU 1
+        want, iou = ho.nms_rotated(boxes, scores, thresh, pre, post)
+        assert n == 0 or float(np.abs(iou[iou > 0] - thresh).min(initial=1.0)) > 1e-4
+        got = ht.rotate_nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), thresh, pre, post).cpu().tolist()
+        assert got == want, (n, thresh)
+        if n >= 200:
+            assert len(want) < min(n, pre or n) or post is not None   # suppression really happens
+    # the reference's calling convention: corner boxes in, the same kept set
+    xyxyr = ht.xywhr2xyxyr(torch.from_numpy(boxes).to(dev))
+    got2 = ht.nms_bev(xyxyr, torch.from_numpy(scores).to(dev), 0.3).cpu().tolist()
+    xywhr = torch.stack(((xyxyr[:, 0] + xyxyr[:, 2]) / 2, (xyxyr[:, 1] + xyxyr[:, 3]) / 2, xyxyr[:, 2] - xyxyr[:, 0],
+                         xyxyr[:, 3] - xyxyr[:, 1], xyxyr[:, 4]), -1).cpu().numpy()
+    assert got2 == ho.nms_rotated(xywhr, scores, 0.3)[0]
+
+
+def test_rotate_nms_large_is_consistent(dev):
+    """4096 boxes (the ABI maximum): the kept set is an independent set of the IoU > thresh graph and every dropped box is
+    covered by a kept box with a higher score (checked with a sampled fp64 IoU on the CPU)."""
+    rs = np.random.RandomState(5)
+    boxes, scores = _nms_boxes(rs, 4096)
+    keep = ht.rotate_nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 0.2).cpu().numpy()
+    assert 100 < len(keep) < 4096 and len(set(keep.tolist())) == len(keep)
+    assert (np.diff(scores[keep]) <= 0).all()
+    sub = keep[:60]
+    iou = ho.box_iou_rotated(boxes[sub], boxes[sub])
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= 0.2 + 1e-4
+    dropped = np.setdiff1d(np.arange(4096), keep)[:40]
+    for j in dropped:
+        higher = keep[scores[keep] >= scores[j]]
+        near = higher[np.abs(boxes[higher, :2] - boxes[j, :2]).max(1) < 8]
+        assert ho.box_iou_rotated(boxes[j:j + 1], boxes[near]).max() > 0.2 - 1e-4
+
+
 def test_heuristic_assigner_matches_oracle(dev):
     boxes, labels, pred, logits = scene(7000, 30)
     qlab = np.random.RandomState(0).randint(0, 10, len(pred))
@@ -294,3 +346,16 @@ def test_predict_with_circle_nms(dev):
         assert ra["bboxes_3d"].shape[0] <= rb["bboxes_3d"].shape[0]
         keep_other = rb["labels_3d"] < 8
         assert int((ra["labels_3d"] < 8).sum()) == int(keep_other.sum())  # classes 0-7 are not suppressed
+    # any other nms_type: rotated-IoU NMS with the task radius as the threshold
+    cfg["test_cfg"] = dict(cfg["test_cfg"], nms_type="rotate", pre_max_size=1000, post_max_size=83)
+    rot = MODELS.build(cfg).to(dev).eval()
+    rot.load_state_dict(head.state_dict())
+    with torch.no_grad():
+        c = rot.predict(feats)
+    for rc, rb in zip(c, b):
+        assert int((rc["labels_3d"] < 8).sum()) == int((rb["labels_3d"] < 8).sum())
+        for cls in (8, 9):
+            sel = rb["labels_3d"] == cls
+            bev = rb["bboxes_3d"][sel][:, [0, 1, 3, 4, 6]].cpu().numpy()
+            want, _ = ho.nms_rotated(bev, rb["scores_3d"][sel].cpu().numpy(), 0.175, 1000, 83)
+            assert int((rc["labels_3d"] == cls).sum()) == len(want)

@@ -134,3 +134,21 @@ def test_losses_against_torch_builtins():
     neg_at = -np.log(1 - pred[0, 0] + 1e-12) * pred[0, 0] ** 2 * 0.5 ** 4
     assert full - ho.gaussian_focal_loss(pred, tg2, avg_factor=1) == pytest.approx(pos - neg_at, rel=1e-9)
     assert ho.l1_loss([[1, 2]], [[0, 4]], [[1, 0.5]], 2) == pytest.approx(1.0)
+
+
+def test_nms_rotated_known_answers():
+    """Hand-computed: axis-aligned overlap 3/5, a 90-degree copy (IoU 1), a far box; pre/post limits; tie order."""
+    b = np.array([[0, 0, 2, 2, 0], [0.5, 0, 2, 2, 0], [5, 5, 1, 1, 0.3], [0, 0, 2, 2, np.pi / 2]], np.float32)
+    s = np.array([0.9, 0.8, 0.7, 0.6], np.float32)
+    keep, iou = ho.nms_rotated(b, s, 0.5)
+    assert keep == [0, 2]
+    np.testing.assert_allclose(iou[0], [0, 0.6, 0, 1.0], atol=1e-6)
+    assert ho.nms_rotated(b, s, 0.65)[0] == [0, 1, 2]          # 0.6 is no longer above the threshold; box 3 falls to box 0
+    assert ho.nms_rotated(b, s, 0.5, pre_max_size=1)[0] == [0]
+    assert ho.nms_rotated(b, s, 0.5, post_max_size=1)[0] == [0]
+    assert ho.nms_rotated(b[[1, 0]], np.array([0.5, 0.5], np.float32), 0.5)[0] == [0]   # tie: lower index first
+    # a 45-degree unit square over an axis-aligned one, same centre: the intersection is a regular octagon of area 2(sqrt2-1)
+    o = ho.box_iou_rotated(np.array([[0, 0, 1, 1, 0]]), np.array([[0, 0, 1, 1, np.pi / 4]]))[0, 0]
+    inter = 2 * (np.sqrt(2) - 1)
+    assert abs(o - inter / (2 - inter)) < 1e-9
+    assert ho.nms_rotated(np.zeros((0, 5)), np.zeros(0), 0.5)[0] == []
