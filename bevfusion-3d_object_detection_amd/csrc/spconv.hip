@@ -742,231 +742,341 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(const float *__restri
     }
 }
 
-// 4 consecutive channels of a feature row as fp32; features are f32 or (IO16) bf16.  Split in two steps so that a group of
-// gathers can be issued back to back and converted afterwards: with the conversion next to the load (inside the
-// predicated block) the compiler waits for each gather before issuing the next -- 8 serialised L2 round trips per K group,
-// measured 1.8x slower than the fp32 kernel.  Invalid lanes load row 0 (always mapped) and are zeroed by a select.
+// 4 consecutive channels of a feature row; features are f32 or (IO16) bf16.  Load and conversion are separate steps so
+// that a group of gathers can be issued back to back and converted afterwards: with the conversion next to a predicated
+// load the compiler waits for each gather before issuing the next (8 serialised L2 round trips per K group, measured
+// 1.8x slower).  Invalid lanes load a valid address (clamped row / channel 0) and are zeroed by a select.
+// The MFMA wgrad kernel.  One wave accumulates a 64 x 64 block of dW[k] over a range of rows.  Per K-step
+// of 4 (input row, output row) pairs every lane loads ONE 4-channel piece of `in` (pair lq, channels 4 la..4 la+3) and ONE
+// of `dout`; the 16 MFMAs (c, d) use element c of the first and element d of the second:
+//   D_cd[a][a'] += in[row][4a+c] * dout[row][4a'+d],  a 64 x 64 block with channel index 4 * lane_id + component,
+// i.e. 2 coalesced loads per 16 MFMAs.  Holes of the rulebook are compacted away first: the pair entries of the wave's
+// whole row range (up to 1024 rows: 16 loads in flight together) go through ballot + prefix popcount into a wave-private
+// LDS list, which one software pipeline then consumes -- the gathers of group g+1 are issued before the 64 MFMAs of
+// group g.  (An earlier version walked 64-row chunks and paid three dependent round trips per chunk.)
+// bf16 rows are read as 8-byte (4-channel) pieces.
+template <bool IO16> struct RawRow { typedef uint4 T; };
+template <> struct RawRow<true> { typedef uint2 T; };
 template <bool IO16>
-__device__ __forceinline__ uint4 ldrow_raw(const void *base, size_t off) {
-  if (IO16) return *(const uint4 *)((const unsigned short *)base + (off & ~(size_t)7));  // aligned 8-channel group
-  return *(const uint4 *)((const float *)base + off);
+__device__ __forceinline__ typename RawRow<IO16>::T ldrow4_raw(const void *base, size_t off);
+template <>
+__device__ __forceinline__ uint4 ldrow4_raw<false>(const void *base, size_t off) { return *(const uint4 *)((const float *)base + off); }
+template <>
+__device__ __forceinline__ uint2 ldrow4_raw<true>(const void *base, size_t off) { return *(const uint2 *)((const unsigned short *)base + off); }
+__device__ __forceinline__ f32x4 ldrow4_cvt(uint4 q, bool ok) {
+  f32x4 r = (f32x4){__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+  return ok ? r : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
-template <bool IO16>
-__device__ __forceinline__ f32x4 ldrow_cvt(uint4 q, size_t off, bool ok) {
-  f32x4 r;
-  if (IO16) {
-    const bool hi = (off & 4) != 0;
-    const unsigned a = hi ? q.z : q.x, b = hi ? q.w : q.y;
-    r = (f32x4){__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16),
-                __uint_as_float(b & 0xffff0000u)};
-  } else {
-    r = (f32x4){__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
-  }
+__device__ __forceinline__ f32x4 ldrow4_cvt(uint2 q, bool ok) {
+  f32x4 r = (f32x4){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                    __uint_as_float(q.y & 0xffff0000u)};
   return ok ? r : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// v2: one wave = (offset k, row split s, 64-ci block, 64-co block).  Per K-step of 4 rows every lane
-// loads ONE float4 of in (row n0+q, channels 4a..4a+3) and ONE float4 of dout; the 16 MFMAs (c,d) then use
-// element c of the first and element d of the second:  D_cd[a][a'] += in[row][4a+c] * dout[row][4a'+d],
-// i.e. a 64x64 block of dW with channel index 4*lane_id + component.  2 coalesced 16-B loads per 16 MFMAs.
-template <bool IO16>
-__global__ __launch_bounds__(256) void spconv_wgrad64_kernel(const void *__restrict__ in, int Cin,
-                                                             const void *__restrict__ dout, int Cout,
-                                                             const int *__restrict__ pairs, int ld,
-                                                             int KV, int n_rows, int S, int GI, int GJ,
-                                                             const int *__restrict__ perm,
-                                                             float *__restrict__ partial) {
-  // workgroup = the 4 row splits s = 4*sg .. 4*sg+3 of one (offset k, 64-ci block gi, 64-co block gj): the four 64 x 64
-  // results are added through LDS in a fixed order and written once (a quarter of the partial-slab traffic)
+// Work decomposition ("stream-K" over rows, weighted by offset): the T = KV * GI * GJ output tiles (64 x 64 each) times
+// Ut = ceil(n_rows / 64) row units form one line, cut into equal runs, one run per workgroup, with exactly as many
+// workgroups as the chip holds at once.  (The earlier grid -- one workgroup per (offset, fixed row split, tile) -- left a
+// long under-occupied tail: the per-wave timeline (tools/wgrad_trace.py) showed the MFMA saturated while all waves were in
+// their loops, but only ~1.2 waves per SIMD alive on average and wave lifetimes comparable to the whole kernel.)
+// Offsets differ in how many of their rows are paired (the centre of a submanifold rulebook pairs every row, a corner
+// offset ~40 %: 2.4x between the extremes on the nuScenes-like clouds), so a unit of offset k counts w_k = 1..64 virtual
+// units, proportional to the offset's pair count (wgrad_offset_counts_kernel, kCountSlices partial counts per offset); a run is q virtual units.  A run covers the
+// end of one tile and the start of the next ones; tile t receives the partial sum of workgroup b in slab b + t of
+// partial[][64][64] (b + t is unique along the staircase of (workgroup, tile) incidences, <= P + T slabs in all).
+struct SkGeom { int Ut, M; };  // M = GI * GJ * Ut: units per offset
+
+constexpr int kCountSlices = 32;  // row slices per offset in the count pass (one workgroup each)
+__global__ __launch_bounds__(256) void wgrad_offset_counts_kernel(const int *__restrict__ pairs, int ld, int n_rows,
+                                                                  int *__restrict__ counts /* [KV][kCountSlices] */) {
+  const int k = blockIdx.x / kCountSlices, sl = blockIdx.x % kCountSlices;
+  const int per = (((n_rows + kCountSlices - 1) / kCountSlices) + 3) & ~3;
+  const int i0 = sl * per, i1 = min(n_rows, i0 + per);
+  const int *row = pairs + (size_t)k * ld;
+  const bool v4 = (ld & 3) == 0 && ((uintptr_t)pairs & 15) == 0;  // 16-byte loads when the table's rows are aligned
+  int c = 0;
+  for (int i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+    if (v4 && i + 3 < i1) {
+      const int4 v = *(const int4 *)(row + i);
+      c += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
+    } else {
+      for (int j = i; j < min(i + 4, i1); ++j) c += row[j] >= 0;
+    }
+  }
+  __shared__ int part[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// weights and their prefix in LDS (s_w[64], s_wpre[65]); executed by the first wave, the caller synchronises
+__device__ __forceinline__ void sk_make_plan(const int *__restrict__ counts, int KV, int *s_w, int *s_wpre) {
+  const int lane = threadIdx.x;
+  int c = 0;
+  if (counts && lane < KV) {
+#pragma unroll
+    for (int j = 0; j < kCountSlices; j += 4) {
+      const int4 v = *(const int4 *)(counts + lane * kCountSlices + j);
+      c += v.x + v.y + v.z + v.w;
+    }
+  }
+  int mx = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+  int w = lane < KV ? ((counts && mx > 0) ? max(1, (int)(((long long)c * 64 + mx - 1) / mx)) : 1) : 0;
+  int incl = w;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  s_w[lane] = w;
+  s_wpre[lane + 1] = incl;
+  if (lane == 0) s_wpre[0] = 0;
+}
+
+// R = 1: 64 x 64 tiles of any Cin x Cout.  R = 2 | 4: the narrow stages (Cin == Cout == C = 64 / R), where a 64 x 64 MFMA
+// block would be 1/4 or 1/16 useful: the 16 lane columns hold R row groups of C/4 channel vectors -- lane la = (r, a) loads
+// channels 4a..4a+3 of pair (lq, r) -- so one K-step consumes 4R pairs and the block's R diagonal C x C sub-blocks each
+// accumulate their own pairs (the off-diagonal ones mix different pairs and are dropped); the diagonal blocks are summed
+// with cross-lane shuffles in the epilogue.  R times fewer MFMAs and loads per pair.
+template <int R, bool IO16>
+__global__ __launch_bounds__(256, 3) void spconv_wgrad64p_kernel(const void *__restrict__ in, int Cin,
+                                                              const void *__restrict__ dout, int Cout,
+                                                              const int *__restrict__ pairs, int ld,
+                                                              int KV, int n_rows, SkGeom g, int GI, int GJ,
+                                                              const int *__restrict__ perm,
+                                                              const int *__restrict__ counts,
+                                                              float *__restrict__ partial) {
+  typedef typename RawRow<IO16>::T Raw;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int S4 = (S + 3) >> 2;
-  long long blk = blockIdx.x;
-  const int gj = (int)(blk % GJ); blk /= GJ;
-  const int gi = (int)(blk % GI); blk /= GI;
-  const int sg = (int)(blk % S4);
-  const int k = (int)(blk / S4);
-  const int s = sg * 4 + wv;
   const int la = lane & 15, lq = lane >> 4;
-  const int rows_per = (((n_rows + S - 1) / S) + 63) & ~63;
-  const int r0 = s < S ? s * rows_per : 0, r1 = s < S ? min(n_rows, r0 + rows_per) : 0;
-  const int ci = gi * 64 + la * 4, co = gj * 64 + la * 4;
-  const bool ci_ok = ci < Cin, co_ok = co < Cout;  // Cin, Cout multiples of 4 (checked by the host)
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // On-the-fly compaction: each 64-row chunk keeps only its valid (input row, output row) pairs of offset k
-  // (ballot + prefix popcount into a wave-private LDS list), so every MFMA K-step carries 4 real pairs instead
-  // of ~50 % holes at the dense stages (and ~85 % at stage 1).
-  __shared__ int2 s_list[4][64];
+  constexpr int CH = 1024, U = 4;
+  __shared__ int2 s_list[4][CH];  // 32 KB; reused as two 64 x 64 staging tiles by the 4-wave sum
+  __shared__ int s_w[64], s_wpre[65];
   int2 *list = s_list[wv];
-  constexpr int U = 4;  // 16 pairs = 8 gathers in flight per group (U = 8 measured no faster: MFMA issue and gather latency add up at ~2 waves per SIMD)
-  for (int chunk = r0; chunk < r1; chunk += 64) {
-    const int row = chunk + lane;
-    const int pr = row < r1 ? pairs[(size_t)k * ld + (perm ? perm[row] : row)] : -1;
-    const unsigned long long vmask = __ballot(pr >= 0);
-    const int cnt = __popcll(vmask);
-    if (cnt == 0) continue;
-    if (pr >= 0) list[__popcll(vmask & ((1ull << lane) - 1ull))] = make_int2(pr, perm ? perm[row] : row);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int t0 = 0; t0 < cnt; t0 += 4 * U) {
-      int2 e[U];
+  if (wv == 0) sk_make_plan(counts, KV, s_w, s_wpre);
+  __syncthreads();
+  const long long V = (long long)g.M * s_wpre[KV];                 // virtual units in all
+  const long long q = (V + gridDim.x - 1) / gridDim.x;            // per workgroup
+  const long long x0 = (long long)blockIdx.x * q, x1 = min(x0 + q, V);
+#ifdef BFHIP_WGRAD_TRACE
+  unsigned long long tr_t0 = wall_clock64(), tr_t1 = 0, tr_t2 = 0;
+  int tr_cnt = 0, tr_k = 0;
+#endif
+  for (long long x = x0; x < x1;) {  // block-uniform: the segments of this run, one per tile touched
+    const int target = (int)(x / g.M);
+    const int k = (int)__popcll(__ballot(lane < KV && s_wpre[lane + 1] <= target));
+    const int wk = s_w[k];
+    const long long L = (long long)g.Ut * wk;                      // virtual length of one tile of offset k
+    const long long xk = x - (long long)g.M * s_wpre[k];           // position inside offset k
+    const int ti = (int)(xk / L);
+    const long long xr = xk - (long long)ti * L, xe = min(L, xr + (x1 - x));
+    const int u0 = (int)(xr / wk), u1 = xe == L ? g.Ut : (int)(xe / wk);
+    const int nu = u1 - u0;  // may be 0: the slab is written all the same (the reduction reads it)
+    x += xe - xr;
+    const int t = k * GI * GJ + ti;
+    const int gj = ti % GJ, gi = ti / GJ;
+    // the segment's units split over the 4 waves (contiguous, the first nu % 4 waves take one more)
+    const int ub = nu >> 2, ur = nu & 3;
+    const int wu0 = u0 + wv * ub + min(wv, ur), wu1 = wu0 + ub + (wv < ur ? 1 : 0);
+    const int r0 = wu0 * 64, r1 = min(wu1 * 64, n_rows);
+    constexpr int AV = 16 / R;  // channel vectors per row group
+    const int ci = R == 1 ? gi * 64 + la * 4 : (la % AV) * 4, co = R == 1 ? gj * 64 + la * 4 : (la % AV) * 4;
+    const bool ci_ok = ci < Cin, co_ok = co < Cout;  // Cin, Cout multiples of 4 (checked by the host)
+    const int cic = ci_ok ? ci : 0, coc = co_ok ? co : 0;  // lanes past the channel count read channel 0 and are zeroed
+    const int jl = R == 1 ? lq : lq * R + la / AV;         // this lane's pair inside a K-step of 4R pairs
+    f32x4 acc[4][4];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int j = t0 + 4 * u + lq;
-        e[u] = j < cnt ? list[j] : make_int2(-1, -1);
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int *prow = pairs + (size_t)k * ld;
+    const int rlast = r1 > 0 ? r1 - 1 : 0;
+    for (int chunk = r0; chunk < r1; chunk += CH) {  // one pass for the usual run lengths (<= 1024 rows per wave)
+      // pair entries of the whole chunk: 16 unconditional loads from clamped rows, back to back -> one round trip
+      int pr[CH / 64], orow[CH / 64];
+#pragma unroll
+      for (int qq = 0; qq < CH / 64; ++qq) orow[qq] = min(chunk + qq * 64 + lane, rlast);
+      if (perm) {
+#pragma unroll
+        for (int qq = 0; qq < CH / 64; ++qq) orow[qq] = perm[orow[qq]];
       }
-      f32x4 av[U], bv[U];
-      uint4 ra[U], rb[U];
-      size_t oa[U], ob[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {  // all gathers of the group in flight together
-        oa[u] = (e[u].x >= 0 && ci_ok) ? (size_t)e[u].x * Cin + ci : 0;
-        ob[u] = (e[u].x >= 0 && co_ok) ? (size_t)e[u].y * Cout + co : 0;
-        ra[u] = ldrow_raw<IO16>(in, oa[u]);
-        rb[u] = ldrow_raw<IO16>(dout, ob[u]);
+      for (int qq = 0; qq < CH / 64; ++qq) pr[qq] = prow[orow[qq]];
+      int cnt = 0;
+#pragma unroll
+      for (int qq = 0; qq < CH / 64; ++qq) {
+        const bool ok1 = chunk + qq * 64 + lane < r1 && pr[qq] >= 0;
+        const unsigned long long vmask = __ballot(ok1);
+        if (ok1) list[cnt + __popcll(vmask & ((1ull << lane) - 1ull))] = make_int2(pr[qq], orow[qq]);
+        cnt += __popcll(vmask);
       }
+#ifdef BFHIP_WGRAD_TRACE
+      tr_t1 = wall_clock64(); tr_cnt += cnt; tr_k = k;
+#endif
+      if (cnt == 0) continue;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // one continuous software pipeline over the compacted list: the gathers of group g+1 (U K-steps of 4R pairs) are in
+      // flight during the 64 MFMAs of group g
+      Raw ra[U], rb[U];
+      bool ok[U];
+      auto issue = [&](int tt) {  // list entries first (clamped index), then the 2 U gathers back to back
+        int2 e[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        av[u] = ldrow_cvt<IO16>(ra[u], oa[u], e[u].x >= 0 && ci_ok);
-        bv[u] = ldrow_cvt<IO16>(rb[u], ob[u], e[u].x >= 0 && co_ok);
-      }
+        for (int u = 0; u < U; ++u) {
+          const int j = tt + 4 * R * u + jl;
+          ok[u] = j < cnt;
+          e[u] = list[min(j, cnt - 1)];
+        }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (t0 + 4 * u < cnt) {  // wave-uniform: skip K-steps past the end of the compacted list
+        for (int u = 0; u < U; ++u) {
+          ra[u] = ldrow4_raw<IO16>(in, (size_t)e[u].x * Cin + cic);
+          rb[u] = ldrow4_raw<IO16>(dout, (size_t)e[u].y * Cout + coc);
+        }
+      };
+      issue(0);
+      for (int t0 = 0; t0 < cnt; t0 += 4 * R * U) {
+        f32x4 av[U], bv[U];
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
+        for (int u = 0; u < U; ++u) {
+          av[u] = ldrow4_cvt(ra[u], ok[u] && ci_ok);
+          bv[u] = ldrow4_cvt(rb[u], ok[u] && co_ok);
+        }
+        if (t0 + 4 * R * U < cnt) issue(t0 + 4 * R * U);  // wave-uniform
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-              acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
+        for (int u = 0; u < U; ++u) {
+          if (t0 + 4 * R * u < cnt) {  // wave-uniform: skip K-steps past the end of the compacted list
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int d = 0; d < 4; ++d)
+                acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // D layout: row = (lane>>4)*4 + i -> a (ci = 4a + c), col = lane&15 -> a' (co = 4a' + d)
-  __shared__ float red[64 * 64];
-  for (int w = 0; w < 4; ++w) {
-    if (wv == w) {
+#ifdef BFHIP_WGRAD_TRACE
+    tr_t2 = wall_clock64();
+#endif
+    __syncthreads();  // every wave is done with its list: the space becomes staging tiles
+    float *red = (float *)&s_list[0][0];
+    float *dst = partial + ((size_t)blockIdx.x + t) * 4096;  // slab b + t, laid out [64][64] whatever C is
+    if constexpr (R == 1) {
+      // Sum of the 4 waves as a two-level tree through LDS (fixed order: (w0 + w1) + (w2 + w3)), then wave 0 stores the
+      // 64 x 64 block from its registers.  D layout: row = (lane>>4)*4 + i -> a (ci = 4a + c), col = lane&15 -> a'
+      // (co = 4a' + d): for fixed (c, i) a lane's 4 d-values are 4 consecutive co -> one 16-byte store.
+      auto stage = [&](float *tile) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            *(f32x4 *)(tile + ((lq * 4 + i) * 4 + c) * 64 + la * 4) = (f32x4){acc[c][0][i], acc[c][1][i], acc[c][2][i], acc[c][3][i]};
+      };
+      auto fold = [&](const float *tile) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 x4 = *(const f32x4 *)(tile + ((lq * 4 + i) * 4 + c) * 64 + la * 4);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[c][d][i] += x4[d];
+          }
+      };
+      if (wv & 1) stage(red + (wv >> 1) * 4096);    // w1 -> tile 0, w3 -> tile 1
+      __syncthreads();
+      if (!(wv & 1)) fold(red + (wv >> 1) * 4096);  // w0 += w1, w2 += w3
+      __syncthreads();
+      if (wv == 2) stage(red);
+      __syncthreads();
+      if (wv == 0) {
+        fold(red);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            *(f32x4 *)(dst + ((lq * 4 + i) * 4 + c) * 64 + la * 4) = (f32x4){acc[c][0][i], acc[c][1][i], acc[c][2][i], acc[c][3][i]};
+      }
+    } else {
+      // D_cd[m][n]: m = lq*4 + i = (row group m / AV, vector m % AV), n = la = (r', a').  The diagonal block of row group g
+      // sits in lanes with r' == g and m / AV == g; group g's copy of element (vector a, vector a') is `g * step` lanes
+      // above group 0's.  Each wave leaves its C x C sum in LDS, then the 4 are added in a fixed order.
+      constexpr int C = 64 / R, step = 16 * (4 / R) + AV;
+      const bool owner = lq < 4 / R && la < AV;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float *r = red + ((lq * 4 + i) * 4 + c) * 64 + la * 4;
+          f32x4 v4;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) r[d] = (w == 0 ? 0.f : r[d]) + acc[c][d][i];
+          for (int d = 0; d < 4; ++d) {
+            const float tv = acc[c][d][i];
+            float sum = tv;
+#pragma unroll
+            for (int gg = 1; gg < R; ++gg) sum += __shfl(tv, (lane + gg * step) & 63);
+            v4[d] = sum;
+          }
+          if (owner) {
+            const int cii = ((lq * 4 + i) % AV) * 4 + c;  // input channel 4a + c with a = m % AV
+            *(f32x4 *)(red + wv * C * C + cii * C + la * 4) = v4;
+          }
         }
+      __syncthreads();
+      for (int e = threadIdx.x * 4; e < C * C; e += 256 * 4) {
+        f32x4 tsum = *(const f32x4 *)(red + e);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) tsum += *(const f32x4 *)(red + w * C * C + e);  // fixed order
+        *(f32x4 *)(dst + (e / C) * 64 + (e % C)) = tsum;
+      }
     }
-    __syncthreads();
+    __syncthreads();  // the staging tiles become lists again
   }
-  float *dst = partial + ((size_t)sg * KV + k) * Cin * Cout;
-  for (int e = threadIdx.x * 4; e < 64 * 64; e += 256 * 4) {
-    const int cii = gi * 64 + (e >> 6), coo = gj * 64 + (e & 63);
-    if (cii < Cin && coo < Cout) *(f32x4 *)(dst + (size_t)cii * Cout + coo) = *(const f32x4 *)(red + e);
+#ifdef BFHIP_WGRAD_TRACE
+  if (lane == 0) {  // 6 x u64 per wave behind the slabs
+    unsigned long long *tr = (unsigned long long *)(partial + ((size_t)gridDim.x + (size_t)KV * GI * GJ) * 4096 + 64) + ((size_t)blockIdx.x * 4 + wv) * 6;
+    tr[0] = tr_t0; tr[1] = tr_t1; tr[2] = tr_t2; tr[3] = wall_clock64(); tr[4] = (unsigned long long)tr_cnt; tr[5] = ((unsigned long long)tr_k << 32);
   }
+#endif
 }
 
-// v3 for the narrow stages (Cin == Cout == C = 64 / R, R = 4 | 2): the 64 x 64 MFMA block of v2 is 1/16 (C = 16) or 1/4
-// (C = 32) useful there.  Here the 16 lane columns hold R row groups of C/4 channel vectors: lane la = (r, a) loads
-// channels 4a..4a+3 of pair (lq, r), so one K step consumes 4R pairs and the block's R diagonal C x C sub-blocks each
-// accumulate their own pairs (the off-diagonal ones mix different pairs and are dropped).  R times fewer MFMAs and
-// loads per pair; the R diagonal blocks are summed with cross-lane shuffles in the epilogue.
-template <int R, bool IO16>
-__global__ __launch_bounds__(256) void spconv_wgrad_packed_kernel(const void *__restrict__ in,
-                                                                  const void *__restrict__ dout,
-                                                                  const int *__restrict__ pairs, int ld, int KV,
-                                                                  int n_rows, int S, float *__restrict__ partial) {
-  constexpr int C = 64 / R, AV = 16 / R;  // channels, channel vectors per row group
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int S4 = (S + 3) >> 2;
-  const int sg = (int)(blockIdx.x % S4);   // workgroup = row splits 4*sg .. 4*sg+3 of offset k, summed through LDS
-  const int k = (int)(blockIdx.x / S4);
-  const int s = sg * 4 + wv;
-  const int la = lane & 15, lq = lane >> 4;
-  const int r = la / AV, a = la % AV;
-  const int rows_per = (((n_rows + S - 1) / S) + 63) & ~63;
-  const int r0 = s < S ? s * rows_per : 0, r1 = s < S ? min(n_rows, r0 + rows_per) : 0;
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) acc[c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __shared__ int2 s_list[4][64];
-  int2 *list = s_list[wv];
-  constexpr int U = 16 / R;  // K steps per 64-pair chunk (each consumes 4R pairs)
-  for (int chunk = r0; chunk < r1; chunk += 64) {
-    const int row = chunk + lane;
-    const int pr = row < r1 ? pairs[(size_t)k * ld + row] : -1;
-    const unsigned long long vmask = __ballot(pr >= 0);
-    const int cnt = __popcll(vmask);
-    if (cnt == 0) continue;
-    if (pr >= 0) list[__popcll(vmask & ((1ull << lane) - 1ull))] = make_int2(pr, row);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    f32x4 av[U], bv[U];
-    uint4 ra[U], rb[U];
-    size_t oa[U], ob[U];
-    bool okv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {  // all gathers of the chunk in flight together
-      const int j = 4 * R * u + lq * R + r;
-      const int2 e = j < cnt ? list[j] : make_int2(-1, -1);
-      okv[u] = e.x >= 0;
-      oa[u] = okv[u] ? (size_t)e.x * C + a * 4 : 0;
-      ob[u] = okv[u] ? (size_t)e.y * C + a * 4 : 0;
-      ra[u] = ldrow_raw<IO16>(in, oa[u]);
-      rb[u] = ldrow_raw<IO16>(dout, ob[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      av[u] = ldrow_cvt<IO16>(ra[u], oa[u], okv[u]);
-      bv[u] = ldrow_cvt<IO16>(rb[u], ob[u], okv[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (4 * R * u < cnt) {  // wave-uniform
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int d = 0; d < 4; ++d)
-            acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // D_cd[m][n]: m = lq*4 + i = (row group m / AV, vector m % AV), n = la = (r', a').  The diagonal block of row group g sits
-  // in lanes with r' == g and m / AV == g; group g's copy of element (vector a, vector a') is `g * step` lanes above group 0's.
-  constexpr int step = 16 * (4 / R) + AV;
-  __shared__ float red[4][C * C];
-  const bool owner = lq < 4 / R && la < AV;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 v;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        float t = acc[c][d][i];
-        float sum = t;
-#pragma unroll
-        for (int g = 1; g < R; ++g) sum += __shfl(t, (lane + g * step) & 63);
-        v[d] = sum;
-      }
-      if (owner) {
-        const int cii = ((lq * 4 + i) % AV) * 4 + c;  // input channel 4a + c with a = m % AV
-        *(f32x4 *)(red[wv] + cii * C + la * 4) = v;
-      }
-    }
+// dW[co][k][ci] = sum over the workgroups b whose run touched tile t(k, ci / 64, co / 64) of partial[b + t][ci % 64][co % 64]
+__global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(const float *__restrict__ partial, int KV, int Cin, int Cout,
+                                                              int GI, int GJ, SkGeom g, int P, const int *__restrict__ counts,
+                                                              float *__restrict__ dW) {
+  // 64 consecutive elements per workgroup, the slabs of each dealt to 4 thread groups (j = jl, jl + 4, ...) and the 4
+  // sums added in a fixed order: a narrow layer has few elements and ~30 slabs per tile, one thread per element would
+  // walk them one dependent load at a time
+  __shared__ int s_w[64], s_wpre[65];
+  __shared__ float s_sum[4][64];
+  if (threadIdx.x < 64) sk_make_plan(counts, KV, s_w, s_wpre);
   __syncthreads();
-  float *dst = partial + ((size_t)sg * KV + k) * C * C;
-  for (int e = threadIdx.x * 4; e < C * C; e += 256 * 4) {
-    f32x4 t = *(const f32x4 *)(red[0] + e);
-#pragma unroll
-    for (int w = 1; w < 4; ++w) t += *(const f32x4 *)(red[w] + e);  // fixed order
-    *(f32x4 *)(dst + e) = t;
+  const int el = threadIdx.x & 63, jl = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + el;
+  const bool live = e < (long long)KV * Cin * Cout;
+  float acc = 0.f;
+  int co = 0, ci = 0, k = 0;
+  if (live) {
+    co = (int)(e % Cout);
+    const long long r = e / Cout;
+    ci = (int)(r % Cin); k = (int)(r / Cin);
+    const int ti = (ci >> 6) * GJ + (co >> 6), t = k * GI * GJ + ti;
+    const long long V = (long long)g.M * s_wpre[KV], q = (V + P - 1) / P;
+    const long long L = (long long)g.Ut * s_w[k], vs = (long long)g.M * s_wpre[k] + (long long)ti * L;
+    const long long first = vs / q, last = (vs + L - 1) / q;
+    const float *src = partial + ((size_t)first + t) * 4096 + (ci & 63) * 64 + (co & 63);
+    const int J = (int)(last - first) + 1;
+    float a0 = 0.f, a1 = 0.f;
+    int j = jl;
+    for (; j + 4 < J; j += 8) { a0 += src[(size_t)j * 4096]; a1 += src[(size_t)(j + 4) * 4096]; }
+    if (j < J) a0 += src[(size_t)j * 4096];
+    acc = a0 + a1;
   }
+  s_sum[jl][el] = acc;
+  __syncthreads();
+  if (live && jl == 0) dW[((size_t)co * KV + k) * Cin + ci] = (s_sum[0][el] + s_sum[1][el]) + (s_sum[2][el] + s_sum[3][el]);
 }
 
 // dW[co][k][ci] = sum_s partial[s][k][ci][co]   (fixed order -> deterministic)
@@ -1403,10 +1513,40 @@ static inline int wgrad_splits(int KV, int GI, int GJ, int n_rows) {
   return S;
 }
 
+// ---- geometry of the row-streamed kernel (see spconv_wgrad64p_kernel)
+static int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else { (void)hipGetLastError(); n = 256; }
+  }
+  return n;
+}
+constexpr int kSkMaxBlocksPerCu = 4;
+template <int R, bool IO16>
+static int wgrad_sk_resident_blocks() {  // workgroups the chip holds at once: the grid of the streamed kernel
+  static int p = 0;
+  if (p == 0) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (spconv_wgrad64p_kernel<R, IO16>), 256, 0) != hipSuccess || occ < 1) {
+      (void)hipGetLastError();
+      occ = 2;
+    }
+    const char *e = getenv("BFHIP_WGRAD_BLOCKS_PER_CU");  // tuning knob (tools/wgrad_trace.py)
+    if (e && atoi(e) > 0) occ = atoi(e);
+    if (occ > kSkMaxBlocksPerCu) occ = kSkMaxBlocksPerCu;
+    p = occ * device_cus();
+  }
+  return p;
+}
 BFHIP_EXPORT size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout, int n_rows) {
   int GI = (Cin + 63) / 64, GJ = (Cout + 63) / 64;
   int S = wgrad_splits(KV, GI, GJ, n_rows);
-  return align_up((size_t)S * KV * Cin * Cout * sizeof(float), 256) + 256;  // the vector kernels use (S + 3) / 4 slabs of it
+  size_t uniform = (size_t)S * KV * Cin * Cout * sizeof(float);  // the scalar-load kernel: one slab per row split
+  // the streamed 64 x 64 kernel: one slab per (workgroup, tile) incidence + the per-offset pair counts
+  size_t streamed = ((size_t)kSkMaxBlocksPerCu * device_cus() + (size_t)KV * GI * GJ) * 4096 * sizeof(float) + 64 * kCountSlices * sizeof(int);
+  return align_up(uniform > streamed ? uniform : streamed, 256) + 256;
 }
 
 BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int32_t *pairs, int ld, int KV,
@@ -1422,34 +1562,46 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
   BFHIP_REQUIRE(in && dout && pairs, "spconv_wgrad: null pointer");
   const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)dout % 16 == 0);
   BFHIP_REQUIRE(!io_bf16 || vec, "spconv_wgrad: bf16 features need channel counts that are multiples of 4 (Cin=%d Cout=%d)", Cin, Cout);
-  int GI = vec ? (Cin + 63) / 64 : (Cin + 31) / 32, GJ = (Cout + 63) / 64;
-  int S = wgrad_splits(KV, (Cin + 63) / 64, GJ, n_rows);
+  int GI = (Cin + 63) / 64, GJ = (Cout + 63) / 64;
+  int S = wgrad_splits(KV, GI, GJ, n_rows);
   if (workspace_bytes < bfhip_spconv_wgrad_workspace_bytes(KV, Cin, Cout, n_rows) || !workspace) { set_error("spconv_wgrad: workspace too small"); return BFHIP_E_WORKSPACE; }
   float *partial = (float *)workspace;
-  long long waves = (long long)KV * S * GI * GJ;
   ProfScope ps;
-  prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
-  const bool packed = vec && Cin == Cout && (Cin == 16 || Cin == 32) && perm == nullptr;
-  const int S4 = (S + 3) / 4;  // the vector kernels sum 4 row splits per workgroup through LDS
-  const dim3 pgrid((unsigned)((long long)KV * S4)), wgrid((unsigned)((long long)KV * S4 * GI * GJ));
-  int slabs = S4;
-  if (packed && Cin == 16) {
-    if (io_bf16) hipLaunchKernelGGL((spconv_wgrad_packed_kernel<4, true>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
-    else hipLaunchKernelGGL((spconv_wgrad_packed_kernel<4, false>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
-  } else if (packed) {
-    if (io_bf16) hipLaunchKernelGGL((spconv_wgrad_packed_kernel<2, true>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
-    else hipLaunchKernelGGL((spconv_wgrad_packed_kernel<2, false>), pgrid, dim3(256), 0, stream, in, dout, pairs, ld, KV, n_rows, S, partial);
-  } else if (vec) {
-    if (io_bf16) hipLaunchKernelGGL(spconv_wgrad64_kernel<true>, wgrid, dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
-    else hipLaunchKernelGGL(spconv_wgrad64_kernel<false>, wgrid, dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, n_rows, S, GI, GJ, perm, partial);
-  } else {
-    slabs = S;
-    hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, (const float *)in, Cin, (const float *)dout, Cout,
-                       pairs, ld, KV, n_rows, S, GI, GJ, partial);
+  if (vec && KV <= 64) {
+    // the row-streamed MFMA kernel: R = 4 | 2 for the narrow square stages (C = 16 | 32), 64 x 64 tiles otherwise
+    const int R = (Cin == Cout && Cin == 16) ? 4 : (Cin == Cout && Cin == 32) ? 2 : 1;
+    int P = R == 4 ? (io_bf16 ? wgrad_sk_resident_blocks<4, true>() : wgrad_sk_resident_blocks<4, false>())
+          : R == 2 ? (io_bf16 ? wgrad_sk_resident_blocks<2, true>() : wgrad_sk_resident_blocks<2, false>())
+                   : (io_bf16 ? wgrad_sk_resident_blocks<1, true>() : wgrad_sk_resident_blocks<1, false>());
+    SkGeom g;
+    g.Ut = (n_rows + 63) / 64;
+    g.M = GI * GJ * g.Ut;
+    const long long units = (long long)KV * g.M;
+    if (units < P) P = (int)units;  // tiny layers: one unit per workgroup at most
+    // per-offset pair counts (weights of the decomposition) behind the slabs
+    int *counts = (int *)(partial + ((size_t)P + (size_t)KV * GI * GJ) * 4096);
+    hipLaunchKernelGGL(wgrad_offset_counts_kernel, dim3(KV * kCountSlices), dim3(256), 0, stream, pairs, ld, n_rows, counts);
+    prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
+#define BFHIP_WG_LAUNCH(RR, IO)                                                                                          \
+  hipLaunchKernelGGL((spconv_wgrad64p_kernel<RR, IO>), dim3(P), dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, \
+                     n_rows, g, GI, GJ, perm, counts, partial)
+    if (R == 4) { if (io_bf16) BFHIP_WG_LAUNCH(4, true); else BFHIP_WG_LAUNCH(4, false); }
+    else if (R == 2) { if (io_bf16) BFHIP_WG_LAUNCH(2, true); else BFHIP_WG_LAUNCH(2, false); }
+    else { if (io_bf16) BFHIP_WG_LAUNCH(1, true); else BFHIP_WG_LAUNCH(1, false); }
+#undef BFHIP_WG_LAUNCH
+    prof_end(&ps);  // the events bracket the dominant kernel only, so their average matches rocprof's for that kernel
+    hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3(ceil_div((long long)KV * Cin * Cout, 64)), dim3(256), 0, stream, partial, KV, Cin, Cout, GI, GJ, g, P, counts, dW);
+    return check_launch("spconv_wgrad");
   }
-  prof_end(&ps);  // the events bracket the dominant kernel only, so their average matches rocprof's for that kernel
+  // channel counts that are not multiples of 4 (the 5-channel input layer) or more than 64 offsets: scalar-load kernel
+  GI = (Cin + 31) / 32;
+  const long long waves = (long long)KV * S * GI * GJ;
+  prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
+  hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, (const float *)in, Cin, (const float *)dout, Cout,
+                     pairs, ld, KV, n_rows, S, GI, GJ, partial);
+  prof_end(&ps);
   long long total = (long long)KV * Cin * Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, partial, slabs, KV, Cin, Cout, dW);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, partial, S, KV, Cin, Cout, dW);
   return check_launch("spconv_wgrad");
 }
 
