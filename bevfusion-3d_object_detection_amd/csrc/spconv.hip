@@ -1203,10 +1203,202 @@ void launch_gemm(int R, int blocks_rows, hipStream_t stream, const float *in, in
     hipLaunchKernelGGL((spconv_gemm_lds_kernel<NT, 4>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
 }
 
+// Pipelined variant of spconv_gemm_bf16_kernel: the same tiling (workgroup = 4 waves x R x 16 output rows, all NT column
+// tiles, one (offset, 32-channel chunk) per step with the weight tile shared through LDS), restructured around latency.
+// The original issued the gathers and the weight-tile loads of step s+1 during step s: one step is only NT * R MFMAs
+// (0.1-0.4 us), so most of every ~1 us round trip was exposed, 27 * CC times per workgroup.  Here
+//  * all pair-table entries of the workgroup's rows are fetched once, back to back, into LDS (s_idx) -- no dependent
+//    index load remains inside the loop;
+//  * loads run TWO steps ahead: three register sets used cyclically (the loop is unrolled by 3 so that no set is copied
+//    while its loads are in flight), gathers are unconditional from clamped addresses and masked when consumed.
+template <int NT, int R, bool IO16>
+__global__ __launch_bounds__(256) void spconv_gemm_bf16p_kernel(const void *__restrict__ in_, int Kdim,
+                                                                const bf16x8 *__restrict__ Wp,
+                                                                const int *__restrict__ pairs, int ld,
+                                                                int KV, int n_rows, int Ndim,
+                                                                const int *__restrict__ perm,
+                                                                const unsigned *__restrict__ row_mask,
+                                                                void *__restrict__ out_) {
+  const float *in = (const float *)in_;
+  const __bf16 *in16 = (const __bf16 *)in_;
+  float *out = (float *)out_;
+  __bf16 *out16 = (__bf16 *)out_;
+  __shared__ bf16x8 sB[2][NT * 64];
+  __shared__ unsigned s_mask;
+  __shared__ int s_idx[4][32][16 * R];  // [wave][offset][row of the wave]; KV <= 32 (checked by the host)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const long long row_base = ((long long)blockIdx.x * 4 + wv) * (R * 16);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int CC = (Kdim + 31) >> 5;
+  if (tid == 0) s_mask = 0u;
+  __syncthreads();
+  int my_row[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    long long sp = row_base + r * 16 + lr;
+    my_row[r] = sp < n_rows ? (perm ? perm[sp] : (int)sp) : -1;
+  }
+  // pair entries of this wave's rows for every offset: lane (lr, lq) takes offsets lq, lq + 4, ...
+  {
+    int v[8][R];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int kk = min(lq + 4 * j, KV - 1);
+        v[j][r] = pairs[(size_t)kk * ld + max(my_row[r], 0)];
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (lq + 4 * j < KV) s_idx[wv][lq + 4 * j][r * 16 + lr] = my_row[r] >= 0 ? v[j][r] : -1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  unsigned wmask = 0u;
+  if (row_mask) {
+    unsigned mm = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) mm |= my_row[r] >= 0 ? row_mask[my_row[r]] : 0u;
+    for (int o = 32; o > 0; o >>= 1) mm |= __shfl_xor(mm, o);
+    wmask = mm;
+  } else {
+    for (int k = 0; k < KV; ++k) {
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) any |= s_idx[wv][k][r * 16 + lr] >= 0;
+      if (__any(any)) wmask |= 1u << k;
+    }
+  }
+  if (lane == 0 && wmask) atomicOr(&s_mask, wmask);
+  __syncthreads();
+  const unsigned gmask = s_mask;
+
+  f32x4 acc[R][NT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int LOADS = (NT * 64 + 255) / 256;
+  struct Set {  // what one step needs from memory
+    bf16x8 pre[LOADS];
+    f32x4 lo[R], hi[R];
+    int ix[R];
+  };
+  auto next_set = [&](int kk) {
+    unsigned rest = gmask & ~((2u << kk) - 1u);
+    return rest ? __ffs(rest) - 1 : KV;
+  };
+  auto advance = [&](int &k, int &cc) {
+    if (++cc == CC) { cc = 0; k = next_set(k); }
+  };
+  auto issue = [&](Set &st, int k, int cc) {  // weight tile of (k, cc) and the gathered operand rows; no waits
+    const bf16x8 *wp = Wp + ((size_t)(k * CC + cc) * NT) * 64;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int e = tid + i * 256;
+      st.pre[i] = wp[e < NT * 64 ? e : 0];
+    }
+    const int ch = cc * 32 + lq * 8;
+    const int chc = ch < Kdim ? ch : 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ix = s_idx[wv][k][r * 16 + lr];
+      st.ix[r] = ch < Kdim ? ix : -1;
+      const size_t off = (size_t)max(ix, 0) * Kdim + chc;
+      if (IO16) {
+        st.lo[r] = *(const f32x4 *)(in16 + off);  // 8 bf16 carried in one 16-byte register group
+      } else {
+        st.lo[r] = *(const f32x4 *)(in + off);
+        st.hi[r] = *(const f32x4 *)(in + off + 4);
+      }
+    }
+  };
+  int buf = 0;
+  auto step = [&](Set &cur, Set &dst, int k, int k2, int cc2) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int e = tid + i * 256;
+      if (e < NT * 64) sB[buf][e] = cur.pre[i];
+    }
+    __syncthreads();
+    if (k2 < KV) issue(dst, k2, cc2);  // block-uniform: two steps ahead
+    if ((wmask >> k) & 1u) {
+      bf16x8 a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (IO16) {
+          a[r] = __builtin_bit_cast(bf16x8, cur.ix[r] >= 0 ? cur.lo[r] : (f32x4){0.f, 0.f, 0.f, 0.f});
+        } else {
+          const f32x4 l = cur.ix[r] >= 0 ? cur.lo[r] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          const f32x4 h = cur.ix[r] >= 0 ? cur.hi[r] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          a[r][0] = (__bf16)l[0]; a[r][1] = (__bf16)l[1]; a[r][2] = (__bf16)l[2]; a[r][3] = (__bf16)l[3];
+          a[r][4] = (__bf16)h[0]; a[r][5] = (__bf16)h[1]; a[r][6] = (__bf16)h[2]; a[r][7] = (__bf16)h[3];
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b = sB[buf][nt * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r], b, acc[r][nt], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  };
+  Set s0, s1, s2;
+  int k0 = gmask ? __ffs(gmask) - 1 : KV, c0 = 0;
+  int k1 = k0, c1 = c0;
+  if (k0 < KV) { issue(s0, k0, c0); advance(k1, c1); }
+  int k2 = k1, c2 = c1;
+  if (k1 < KV) { issue(s1, k1, c1); advance(k2, c2); }
+  while (k0 < KV) {  // k0 / k1 / k2: offsets of the current step and the two after it (KV = none)
+    step(s0, s2, k0, k2, c2);
+    k0 = k1; c0 = c1; k1 = k2; c1 = c2; if (k2 < KV) advance(k2, c2);
+    if (k0 >= KV) break;
+    step(s1, s0, k0, k2, c2);
+    k0 = k1; c0 = c1; k1 = k2; c1 = c2; if (k2 < KV) advance(k2, c2);
+    if (k0 >= KV) break;
+    step(s2, s1, k0, k2, c2);
+    k0 = k1; c0 = c1; k1 = k2; c1 = c2; if (k2 < KV) advance(k2, c2);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = __shfl(my_row[r], lq * 4 + i);
+      if (row >= 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          int col = nt * 16 + lr;
+          if (col < Ndim) {
+            if (IO16) out16[(size_t)row * Ndim + col] = (__bf16)acc[r][nt][i];
+            else out[(size_t)row * Ndim + col] = acc[r][nt][i];
+          }
+        }
+      }
+    }
+}
+
 template <int NT, bool IO16>
 void launch_gemm_bf16(int R, hipStream_t stream, const void *in, int Kdim, const bf16x8 *Wp, const int *pairs,
                       int ld, int KV, int n_rows, int Ndim, const int *perm, const unsigned *row_mask, void *out) {
   auto grid = [&](int r) { return dim3(ceil_div(n_rows, 4 * r * 16)); };
+  // measured on the encoder's layers (tools/gemm_micro.py, bf16 storage): 128 -> 128: 88.8 -> 79.4 us, 64 -> 128: 53.1 -> 46.5,
+  // 64 -> 64: 53.2 -> 52.6; 32 -> 32: 48.1 -> 59.1 and 16 -> 32: 40.0 -> 59.8 (27 one-chunk steps: the up-front index fetch costs
+  // more than the deeper pipeline saves), hence the split at 64 input channels
+  if (Kdim >= 64) {
+    if (R == 1)
+      hipLaunchKernelGGL((spconv_gemm_bf16p_kernel<NT, 1, IO16>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+    else if (R == 2)
+      hipLaunchKernelGGL((spconv_gemm_bf16p_kernel<NT, 2, IO16>), grid(2), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+    else
+      hipLaunchKernelGGL((spconv_gemm_bf16p_kernel<NT, 4, IO16>), grid(4), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
+    return;
+  }
   if (R == 1)
     hipLaunchKernelGGL((spconv_gemm_bf16_kernel<NT, 1, IO16>), grid(1), dim3(256), 0, stream, in, Kdim, Wp, pairs, ld, KV, n_rows, Ndim, perm, row_mask, out);
   else if (R == 2)
