@@ -781,9 +781,16 @@ __device__ __forceinline__ f32x4 ldrow4_cvt(uint2 q, bool ok) {
 // Offsets differ in how many of their rows are paired (the centre of a submanifold rulebook pairs every row, a corner
 // offset ~40 %: 2.4x between the extremes on the nuScenes-like clouds), so a unit of offset k counts w_k = 1..64 virtual
 // units, proportional to the offset's pair count (wgrad_offset_counts_kernel, kCountSlices partial counts per offset); a run is q virtual units.  A run covers the
-// end of one tile and the start of the next ones; tile t receives the partial sum of workgroup b in slab b + t of
-// partial[][64][64] (b + t is unique along the staircase of (workgroup, tile) incidences, <= P + T slabs in all).
-struct SkGeom { int Ut, M; };  // M = GI * GJ * Ut: units per offset
+// end of one tile and the start of the next ones.
+// XCD-aware order: wgrad walks the feature matrices once per offset (27 passes); in offset-major order every pass misses the
+// 4 MiB L2 of the XCD (PMC: 125 MB fetched per 32-channel launch for 31 MB of operands).  So the rows are cut into NR = 8
+// regions and the line is ordered (region, offset, tile, unit); workgroups are dispatched to XCDs round-robin (h % 8), and
+// the run of workgroup h is run (h % 8) * P/8 + h / 8: XCD x works through region x for all offsets and its L2 only ever
+// sees an eighth of the rows (plus the halo of neighbouring rows).  Line tile tl = region * T + t receives the partial sum
+// of run b in slab b + tl of partial[][64][64] (b + tl is unique along the staircase of (run, line tile) incidences,
+// <= P + NR * T slabs in all).
+struct SkGeom { int Ur, M, NR; };  // Ur = units per region, M = GI * GJ * Ur: units per (region, offset), NR regions
+constexpr int kSkRegions = 8;
 
 constexpr int kCountSlices = 32;  // row slices per offset in the count pass (one workgroup each)
 __global__ __launch_bounds__(256) void wgrad_offset_counts_kernel(const int *__restrict__ pairs, int ld, int n_rows,
@@ -858,30 +865,36 @@ __global__ __launch_bounds__(256, 3) void spconv_wgrad64p_kernel(const void *__r
   int2 *list = s_list[wv];
   if (wv == 0) sk_make_plan(counts, KV, s_w, s_wpre);
   __syncthreads();
-  const long long V = (long long)g.M * s_wpre[KV];                 // virtual units in all
+  const long long VR = (long long)g.M * s_wpre[KV];                // virtual units of one region
+  const long long V = VR * g.NR;                                   // ... in all
   const long long q = (V + gridDim.x - 1) / gridDim.x;            // per workgroup
-  const long long x0 = (long long)blockIdx.x * q, x1 = min(x0 + q, V);
+  // run of this workgroup: XCD x (= blockIdx % 8) takes the x-th eighth of the line when the grid divides evenly
+  const unsigned P8 = gridDim.x >> 3;
+  const long long bl = (gridDim.x & 7) == 0 ? (long long)(blockIdx.x & 7) * P8 + (blockIdx.x >> 3) : (long long)blockIdx.x;
+  const long long x0 = bl * q, x1 = min(x0 + q, V);
 #ifdef BFHIP_WGRAD_TRACE
   unsigned long long tr_t0 = wall_clock64(), tr_t1 = 0, tr_t2 = 0;
   int tr_cnt = 0, tr_k = 0;
 #endif
   for (long long x = x0; x < x1;) {  // block-uniform: the segments of this run, one per tile touched
-    const int target = (int)(x / g.M);
+    const int rg = (int)(x / VR);                                  // region
+    const long long xg = x - (long long)rg * VR;                   // position inside the region
+    const int target = (int)(xg / g.M);
     const int k = (int)__popcll(__ballot(lane < KV && s_wpre[lane + 1] <= target));
     const int wk = s_w[k];
-    const long long L = (long long)g.Ut * wk;                      // virtual length of one tile of offset k
-    const long long xk = x - (long long)g.M * s_wpre[k];           // position inside offset k
+    const long long L = (long long)g.Ur * wk;                      // virtual length of one tile of offset k in a region
+    const long long xk = xg - (long long)g.M * s_wpre[k];          // position inside (region, offset k)
     const int ti = (int)(xk / L);
     const long long xr = xk - (long long)ti * L, xe = min(L, xr + (x1 - x));
-    const int u0 = (int)(xr / wk), u1 = xe == L ? g.Ut : (int)(xe / wk);
+    const int u0 = rg * g.Ur + (int)(xr / wk), u1 = rg * g.Ur + (xe == L ? g.Ur : (int)(xe / wk));
     const int nu = u1 - u0;  // may be 0: the slab is written all the same (the reduction reads it)
     x += xe - xr;
-    const int t = k * GI * GJ + ti;
+    const int t = (rg * KV + k) * GI * GJ + ti;                    // line tile
     const int gj = ti % GJ, gi = ti / GJ;
     // the segment's units split over the 4 waves (contiguous, the first nu % 4 waves take one more)
     const int ub = nu >> 2, ur = nu & 3;
     const int wu0 = u0 + wv * ub + min(wv, ur), wu1 = wu0 + ub + (wv < ur ? 1 : 0);
-    const int r0 = wu0 * 64, r1 = min(wu1 * 64, n_rows);
+    const int r0 = min(wu0 * 64, n_rows), r1 = min(wu1 * 64, n_rows);  // the last region is padded past n_rows
     constexpr int AV = 16 / R;  // channel vectors per row group
     const int ci = R == 1 ? gi * 64 + la * 4 : (la % AV) * 4, co = R == 1 ? gj * 64 + la * 4 : (la % AV) * 4;
     const bool ci_ok = ci < Cin, co_ok = co < Cout;  // Cin, Cout multiples of 4 (checked by the host)
@@ -964,7 +977,7 @@ __global__ __launch_bounds__(256, 3) void spconv_wgrad64p_kernel(const void *__r
 #endif
     __syncthreads();  // every wave is done with its list: the space becomes staging tiles
     float *red = (float *)&s_list[0][0];
-    float *dst = partial + ((size_t)blockIdx.x + t) * 4096;  // slab b + t, laid out [64][64] whatever C is
+    float *dst = partial + ((size_t)bl + t) * 4096;  // slab b + tl, laid out [64][64] whatever C is
     if constexpr (R == 1) {
       // Sum of the 4 waves as a two-level tree through LDS (fixed order: (w0 + w1) + (w2 + w3)), then wave 0 stores the
       // 64 x 64 block from its registers.  D layout: row = (lane>>4)*4 + i -> a (ci = 4a + c), col = lane&15 -> a'
@@ -1036,7 +1049,7 @@ __global__ __launch_bounds__(256, 3) void spconv_wgrad64p_kernel(const void *__r
   }
 #ifdef BFHIP_WGRAD_TRACE
   if (lane == 0) {  // 6 x u64 per wave behind the slabs
-    unsigned long long *tr = (unsigned long long *)(partial + ((size_t)gridDim.x + (size_t)KV * GI * GJ) * 4096 + 64) + ((size_t)blockIdx.x * 4 + wv) * 6;
+    unsigned long long *tr = (unsigned long long *)(partial + ((size_t)gridDim.x + (size_t)g.NR * KV * GI * GJ) * 4096 + 64 * kCountSlices) + ((size_t)blockIdx.x * 4 + wv) * 6;
     tr[0] = tr_t0; tr[1] = tr_t1; tr[2] = tr_t2; tr[3] = wall_clock64(); tr[4] = (unsigned long long)tr_cnt; tr[5] = ((unsigned long long)tr_k << 32);
   }
 #endif
@@ -1046,8 +1059,8 @@ __global__ __launch_bounds__(256, 3) void spconv_wgrad64p_kernel(const void *__r
 __global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(const float *__restrict__ partial, int KV, int Cin, int Cout,
                                                               int GI, int GJ, SkGeom g, int P, const int *__restrict__ counts,
                                                               float *__restrict__ dW) {
-  // 64 consecutive elements per workgroup, the slabs of each dealt to 4 thread groups (j = jl, jl + 4, ...) and the 4
-  // sums added in a fixed order: a narrow layer has few elements and ~30 slabs per tile, one thread per element would
+  // 64 consecutive elements per workgroup, the regions of each dealt to 4 thread groups (region = jl, jl + 4, ...) and the
+  // 4 sums added in a fixed order: a narrow layer has few elements and ~30 slabs per tile, one thread per element would
   // walk them one dependent load at a time
   __shared__ int s_w[64], s_wpre[65];
   __shared__ float s_sum[4][64];
@@ -1062,17 +1075,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(const float *__res
     co = (int)(e % Cout);
     const long long r = e / Cout;
     ci = (int)(r % Cin); k = (int)(r / Cin);
-    const int ti = (ci >> 6) * GJ + (co >> 6), t = k * GI * GJ + ti;
-    const long long V = (long long)g.M * s_wpre[KV], q = (V + P - 1) / P;
-    const long long L = (long long)g.Ut * s_w[k], vs = (long long)g.M * s_wpre[k] + (long long)ti * L;
-    const long long first = vs / q, last = (vs + L - 1) / q;
-    const float *src = partial + ((size_t)first + t) * 4096 + (ci & 63) * 64 + (co & 63);
-    const int J = (int)(last - first) + 1;
-    float a0 = 0.f, a1 = 0.f;
-    int j = jl;
-    for (; j + 4 < J; j += 8) { a0 += src[(size_t)j * 4096]; a1 += src[(size_t)(j + 4) * 4096]; }
-    if (j < J) a0 += src[(size_t)j * 4096];
-    acc = a0 + a1;
+    const int ti = (ci >> 6) * GJ + (co >> 6), T = KV * GI * GJ;
+    const long long VR = (long long)g.M * s_wpre[KV], V = VR * g.NR, q = (V + P - 1) / P;
+    const long long L = (long long)g.Ur * s_w[k];
+    const float *base = partial + (ci & 63) * 64 + (co & 63);
+    for (int rg = jl; rg < g.NR; rg += 4) {
+      const long long vs = (long long)rg * VR + (long long)g.M * s_wpre[k] + (long long)ti * L;
+      const long long first = vs / q, last = (vs + L - 1) / q;
+      const float *src = base + ((size_t)first + (size_t)rg * T + (size_t)k * GI * GJ + ti) * 4096;
+      const int J = (int)(last - first) + 1;
+      float a0 = 0.f, a1 = 0.f;
+      int j = 0;
+      for (; j + 1 < J; j += 2) { a0 += src[(size_t)j * 4096]; a1 += src[(size_t)(j + 1) * 4096]; }
+      if (j < J) a0 += src[(size_t)j * 4096];
+      acc += a0 + a1;
+    }
   }
   s_sum[jl][el] = acc;
   __syncthreads();
@@ -1737,7 +1754,7 @@ BFHIP_EXPORT size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout
   int S = wgrad_splits(KV, GI, GJ, n_rows);
   size_t uniform = (size_t)S * KV * Cin * Cout * sizeof(float);  // the scalar-load kernel: one slab per row split
   // the streamed 64 x 64 kernel: one slab per (workgroup, tile) incidence + the per-offset pair counts
-  size_t streamed = ((size_t)kSkMaxBlocksPerCu * device_cus() + (size_t)KV * GI * GJ) * 4096 * sizeof(float) + 64 * kCountSlices * sizeof(int);
+  size_t streamed = ((size_t)kSkMaxBlocksPerCu * device_cus() + (size_t)kSkRegions * KV * GI * GJ) * 4096 * sizeof(float) + 64 * kCountSlices * sizeof(int);
   return align_up(uniform > streamed ? uniform : streamed, 256) + 256;
 }
 
@@ -1765,13 +1782,18 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
     int P = R == 4 ? (io_bf16 ? wgrad_sk_resident_blocks<4, true>() : wgrad_sk_resident_blocks<4, false>())
           : R == 2 ? (io_bf16 ? wgrad_sk_resident_blocks<2, true>() : wgrad_sk_resident_blocks<2, false>())
                    : (io_bf16 ? wgrad_sk_resident_blocks<1, true>() : wgrad_sk_resident_blocks<1, false>());
+    const int Ut = (n_rows + 63) / 64;
     SkGeom g;
-    g.Ut = (n_rows + 63) / 64;
-    g.M = GI * GJ * g.Ut;
-    const long long units = (long long)KV * g.M;
+    // regions only when each has a few units at least; 4 instead of 8 for 128 x 128 layers (4 tiles per offset): with 8 the
+    // line tiles get shorter than a run and every workgroup flushes twice (measured 93.9 vs 103.8 us), while a quarter
+    // of the rows of the 24 k-row stage (3.1 MB in bf16) still fits the 4 MiB L2
+    g.NR = Ut >= 8 * kSkRegions ? (GI * GJ == 4 ? kSkRegions / 2 : kSkRegions) : 1;
+    g.Ur = (Ut + g.NR - 1) / g.NR;
+    g.M = GI * GJ * g.Ur;
+    const long long units = (long long)g.NR * KV * g.M;
     if (units < P) P = (int)units;  // tiny layers: one unit per workgroup at most
     // per-offset pair counts (weights of the decomposition) behind the slabs
-    int *counts = (int *)(partial + ((size_t)P + (size_t)KV * GI * GJ) * 4096);
+    int *counts = (int *)(partial + ((size_t)P + (size_t)g.NR * KV * GI * GJ) * 4096);
     hipLaunchKernelGGL(wgrad_offset_counts_kernel, dim3(KV * kCountSlices), dim3(256), 0, stream, pairs, ld, n_rows, counts);
     prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
 #define BFHIP_WG_LAUNCH(RR, IO)                                                                                          \

@@ -32,9 +32,11 @@ def trace(C, N, pair_fwd, n_pairs, label):
     occ = int(os.environ["BFHIP_WGRAD_BLOCKS_PER_CU"])   # set it: the library's own choice is not visible from here
     P = occ * torch.cuda.get_device_properties(0).multi_processor_count
     T, Ut = 27 * GI * GJ, (N + 63) // 64
-    P = min(P, T * Ut)
-    nwaves, S = P * 4, -(-T * Ut // P)
-    off = (P + T) * 4096 * 4 + 256
+    NR = (4 if GI * GJ == 4 else 8) if Ut >= 64 else 1       # the library's rule (spconv.hip, bfhip_spconv_wgrad)
+    Ur = -(-Ut // NR)
+    P = min(P, NR * T * Ur)
+    nwaves, S = P * 4, -(-NR * T * Ur // P)
+    off = (P + NR * T) * 4096 * 4 + 64 * 32 * 4
     tr = ws[off:off + nwaves * 48].cpu().numpy().view(np.uint64).reshape(nwaves, 6).astype(np.int64)
     t0 = tr[:, 0].min()
     st, t1, t2, en, cnt, kk = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0, (tr[:, 3] - t0) / 100.0, tr[:, 4], tr[:, 5] >> 32
