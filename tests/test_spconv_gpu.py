@@ -350,3 +350,63 @@ def test_presized_strided_rulebooks_are_identical(dev):
     plans = sp.prepare_strided_rulebooks(c, B, list(shape), specs)
     assert len(plans) == 4
     assert sorted(p.n_out for p in plans.values()) == sorted([m.indices.shape[0] for m in mid0[:3]] + [int((bev0.abs().sum(1) > 0).sum() * 0 + sp.build_sparse_rulebook(mid0[3].indices, B, mid0[3].spatial_shape, *specs[3]).out_indices.shape[0])])
+
+
+def _wgrad_reference(x, g, pairs, n_rows):
+    """dW[co][k][ci] = sum over rows n with pairs[k][n] >= 0 of g[n][co] * x[pairs[k][n]][ci], in fp64."""
+    KV = pairs.shape[0]
+    out = np.zeros((g.shape[1], KV, x.shape[1]))
+    for k in range(KV):
+        rows = np.nonzero(pairs[k, :n_rows] >= 0)[0]
+        if len(rows):
+            out[:, k, :] = g[rows].astype(np.float64).T @ x[pairs[k, rows]].astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,kv,n_rows,use_perm", [
+    (16, 16, 27, 1, False), (16, 16, 27, 63, False), (32, 32, 27, 65, True), (64, 64, 27, 4097, False),
+    (64, 128, 27, 5000, True), (128, 64, 3, 4200, False), (128, 128, 27, 9001, False), (96, 40, 1, 700, False),
+    (32, 64, 8, 20000, False), (16, 16, 27, 20011, False), (5, 16, 27, 3000, False)])
+def test_wgrad_abi_geometries_vs_fp64(dev, cin, cout, kv, n_rows, use_perm):
+    """bfhip_spconv_wgrad through the C ABI on pair tables the encoder never produces: single rows, row counts around the
+    64-row unit and the 8-region threshold (64 units), offsets with no pair at all and one that pairs every row, a row
+    permutation, rectangular channel counts; fp32 and bf16 feature storage."""
+    from bevfusion_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(cin * 131 + cout * 7 + kv + n_rows)
+    n_in = max(n_rows // 2, 1)
+    ld = n_rows + rs.randint(0, 5)
+    pairs = np.full((kv, ld), -1, np.int32)
+    for k in range(kv):
+        density = (0.0, 1.0, 0.05, 0.5)[k % 4] if kv > 1 else 0.6   # empty, full, sparse and half-filled offsets
+        m = rs.rand(n_rows) < density
+        pairs[k, :n_rows][m] = rs.randint(0, n_in, int(m.sum()))
+    x = rs.randn(n_in, cin).astype(np.float32)
+    g = rs.randn(n_rows, cout).astype(np.float32)
+    perm = rs.permutation(n_rows).astype(np.int32) if use_perm else None
+    want = _wgrad_reference(x, g, pairs, n_rows)
+    tp, tperm = torch.from_numpy(pairs).to(dev), (torch.from_numpy(perm).to(dev) if use_perm else None)
+    for io16 in (0, 1):
+        if io16 and (cin % 4 or cout % 4):
+            continue
+        tx, tg = torch.from_numpy(x).to(dev), torch.from_numpy(g).to(dev)
+        ref = want
+        if io16:
+            tx, tg = tx.to(torch.bfloat16), tg.to(torch.bfloat16)
+            ref = _wgrad_reference(tx.float().cpu().numpy(), tg.float().cpu().numpy(), pairs, n_rows)
+        dw = torch.full((cout, kv, cin), float("nan"), device=dev)
+        wsb = lib.bfhip_spconv_wgrad_workspace_bytes(kv, cin, cout, n_rows)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.bfhip_spconv_wgrad(_lib.ptr(tx), _lib.ptr(tg), _lib.ptr(tp), ld, kv, n_rows, cin, cout, _lib.ptr(tperm), _lib.ptr(dw),
+                                    io16, _lib.ptr(ws), wsb, _lib.stream_of(tx))
+        _lib.check(rc, "spconv_wgrad")
+        got = dw.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert rel_err(got, ref) < 2e-5, (io16,)
+        if kv > 1:
+            assert (got[:, 0, :] == 0).all()   # the offset without pairs
+        # same inputs, same bits: the partial sums are combined in a fixed order
+        dw2 = torch.empty_like(dw)
+        lib.bfhip_spconv_wgrad(_lib.ptr(tx), _lib.ptr(tg), _lib.ptr(tp), ld, kv, n_rows, cin, cout, _lib.ptr(tperm), _lib.ptr(dw2),
+                               io16, _lib.ptr(ws), wsb, _lib.stream_of(tx))
+        assert torch.equal(dw, dw2)
