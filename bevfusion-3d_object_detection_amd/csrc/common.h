@@ -50,6 +50,19 @@ struct Workspace {
   bool ok() const { return off <= size; }
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap so that each
+// XCD walks one CONTIGUOUS eighth of the work: consecutive intervals (adjacent BEV cells) gather
+// neighbouring feature rows, and consecutive pixels gather neighbouring out_grad rows, so each XCD's
+// 4 MiB L2 then holds its own slice of the gathered table.  Bijective for any grid size; speed only.
+__device__ __forceinline__ long long xcd_chunked_block(long long bid, long long nblocks) {
+  const long long per = (nblocks + 7) / 8;      // blocks per XCD slice (last slices may be short)
+  const long long xcd = bid & 7, slot = bid >> 3;
+  const long long full = nblocks - (per - 1) * 8;  // number of slices that hold `per` blocks (1..8)
+  // slices [0, full) have `per` blocks, the rest have per-1
+  long long base = xcd < full ? xcd * per : full * per + (xcd - full) * (per - 1);
+  return base + slot;
+}
+
 }  // namespace bfhip
 
 #define BFHIP_REQUIRE(cond, ...)                \

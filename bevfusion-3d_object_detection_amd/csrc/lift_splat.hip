@@ -216,19 +216,6 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const int *__restrict
 // ------------------------------------------------------------------------------ fused forward
 constexpr int kU = 8;
 
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap so that each
-// XCD walks one CONTIGUOUS eighth of the work: consecutive intervals (adjacent BEV cells) gather
-// neighbouring feature rows, and consecutive pixels gather neighbouring out_grad rows, so each XCD's
-// 4 MiB L2 then holds its own slice of the gathered table.  Bijective for any grid size; speed only.
-__device__ __forceinline__ long long xcd_chunked_block(long long bid, long long nblocks) {
-  const long long per = (nblocks + 7) / 8;      // blocks per XCD slice (last slices may be short)
-  const long long xcd = bid & 7, slot = bid >> 3;
-  const long long full = nblocks - (per - 1) * 8;  // number of slices that hold `per` blocks (1..8)
-  // slices [0, full) have `per` blocks, the rest have per-1
-  long long base = xcd < full ? xcd * per : full * per + (xcd - full) * (per - 1);
-  return base + slot;
-}
-
 // cq lanes per interval, each lane owns 4 channels.  out[cell][c] = sum_i depth[pix_i, d_i] * feat[pix_i, c]
 __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
     const float *__restrict__ depth, int depth_pitch, const float *__restrict__ feat, int feat_pitch,

@@ -410,3 +410,16 @@ def test_wgrad_abi_geometries_vs_fp64(dev, cin, cout, kv, n_rows, use_perm):
         lib.bfhip_spconv_wgrad(_lib.ptr(tx), _lib.ptr(tg), _lib.ptr(tp), ld, kv, n_rows, cin, cout, _lib.ptr(tperm), _lib.ptr(dw2),
                                io16, _lib.ptr(ws), wsb, _lib.stream_of(tx))
         assert torch.equal(dw, dw2)
+
+
+def test_sort_rows_is_region_major_mask_sort(dev):
+    """bfhip_rulebook_sort_rows: row_mask bit k = pair present; perm = stable sort by (eighth of the row range, mask)."""
+    from bevfusion_amd.spconv import sort_rows
+    rs = np.random.RandomState(4)
+    for n, kv in ((1, 27), (777, 27), (5000, 27), (3000, 3)):
+        pairs = np.where(rs.rand(kv, n) < 0.4, rs.randint(0, n, (kv, n)), -1).astype(np.int32)
+        mask, perm = sort_rows(torch.from_numpy(pairs).to(dev))
+        want_mask = ((pairs >= 0).astype(np.int64) << np.arange(kv)[:, None]).sum(0)
+        np.testing.assert_array_equal(mask.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, want_mask)
+        key = ((np.arange(n, dtype=np.int64) * 8) // n << kv) | want_mask
+        np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind="stable"))
