@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 
 import importlib.util as _ilu  # noqa: E402
 
+# the hosts of this pool only support dmabuf IPC: RCCL between the ranks of a node needs this before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 # MIOpen reads MIOPEN_USER_DB_PATH when it initialises: point it at the shipped tuning db before torch loads
 _spec = _ilu.spec_from_file_location("_bfhip_tuning", os.path.join(ROOT, "bevfusion-3d_object_detection_amd", "tuning", "__init__.py"))
 _tuning = _ilu.module_from_spec(_spec)
