@@ -38,6 +38,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MIOPEN_FIND = os.environ.get("BENCH_MIOPEN_FIND", "0") == "1"
+# gradient exchange between ranks: "flat" = one all-reduce per dtype after the backward (default), "ddp" = torch DDP buckets
+GRAD_SYNC = os.environ.get("BENCH_GRAD_SYNC", "flat")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
 
 
@@ -194,10 +196,17 @@ class _ModelWorkload:
             self.opt = MasterWeightAdamW(self.model, lr=2e-4, weight_decay=0.01, max_grad_norm=35.0)  # before DDP: dtypes fixed
         else:
             self.opt = torch.optim.AdamW(self.model.parameters(), lr=2e-4, weight_decay=0.01, fused=True)
-        if ddp:
+        self.grad_sync = None
+        if ddp and GRAD_SYNC == "ddp":
             from torch.nn.parallel import DistributedDataParallel as DDP
             # BatchNorm statistics stay local (no SyncBN in the reference configs): buffers are not broadcast
             self.step_model = DDP(self.model, device_ids=[local_rank], gradient_as_bucket_view=True, broadcast_buffers=False)
+        elif ddp and GRAD_SYNC != "none":  # "none": process group only (measures what the communicator itself costs)
+            # one flat all-reduce per dtype after the backward (bevfusion_amd/grad_sync.py): the DDP wrapper costs 3 ms of
+            # host time per step on this host-bound model; BatchNorm statistics stay local as under DDP above
+            from bevfusion_amd.grad_sync import FlatGradAllReduce, broadcast_parameters
+            broadcast_parameters(self.model)
+            self.grad_sync = FlatGradAllReduce(self.model.parameters())
         self.parse_losses = BEVFusion.parse_losses
         self._params = [p for p in self.model.parameters() if p.requires_grad]
         # ground truth as a dataloader hands it over: per-frame host tensors (boxes [G, 9], labels [G]), G ~ U(15, 60)
@@ -229,6 +238,8 @@ class _ModelWorkload:
             losses = self.step_model(self.inputs, None, self.gts)
             loss = self.parse_losses(losses)
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.reduce()
         if not self.master_weights:
             torch.nn.utils.clip_grad_norm_(self._params, 35.0, foreach=True)
         self.opt.step()
@@ -365,9 +376,14 @@ class DistSelfTest:
 
         self.tail = Tail(self.fuser, self.backbone, self.neck)
         self.step_model = self.tail
-        if ddp:
+        self.grad_sync = None
+        if ddp and GRAD_SYNC == "ddp":
             from torch.nn.parallel import DistributedDataParallel as DDP
             self.step_model = DDP(self.tail)
+        elif ddp:
+            from bevfusion_amd.grad_sync import FlatGradAllReduce, broadcast_parameters
+            broadcast_parameters(self.tail)
+            self.grad_sync = FlatGradAllReduce(self.tail.parameters())
         self.opt = torch.optim.AdamW(self.tail.parameters(), lr=2e-4)
         g = torch.Generator().manual_seed(seed_base)
         self.a = torch.randn(batch, 8, 24, 24, generator=g)
@@ -377,6 +393,8 @@ class DistSelfTest:
         self.opt.zero_grad(set_to_none=True)
         loss = self.step_model(self.a, self.b).abs().mean()
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.reduce()
         self.opt.step()
         return loss
 
@@ -423,7 +441,9 @@ def main():
         if cpu_mode or one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # no device_id: binding the group to the device at init ("eager" communicator) costs this host-bound step 4 ms
+            # (38.5 plain, 38.8 with the lazily created communicator + flat all-reduce, 42.6 eager, one MI355X, world size 1)
+            dist.init_process_group("nccl")
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
 
     from bevfusion_amd import _lib
@@ -440,7 +460,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if cpu_mode or one_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         if not cpu_mode:
             torch.cuda.synchronize()
 
@@ -510,7 +533,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if getattr(wl, "amp", False) else "f32", "data": "synthetic",
             "config": {"workload": wl.name, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                        "points_per_frame": args.points, "frustum_rows_kept": wl.nk, "bev_intervals": wl.m,
-                       "parallelism": ("dp%d (DDP, RCCL gradient all-reduce)" % world) if world > 1 and hasattr(wl, "step_model")
+                       "parallelism": ("dp%d (%s, RCCL gradient all-reduce)" % (world, "DDP buckets" if GRAD_SYNC == "ddp" else "one flat all-reduce per dtype after the backward")) if world > 1 and hasattr(wl, "step_model")
                        else "independent frames per rank"},
             "roofline": roof, "ops": ops,
         }

@@ -16,8 +16,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(nproc, tmp_path, extra=()):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FINGERPRINT_DIR=str(tmp_path), OMP_NUM_THREADS="2")
+def _run(nproc, tmp_path, extra=(), grad_sync="flat"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FINGERPRINT_DIR=str(tmp_path), OMP_NUM_THREADS="2",
+               BENCH_GRAD_SYNC=grad_sync)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
            "--workload", "dist_selftest", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "2", *extra]
@@ -35,9 +36,16 @@ def test_two_ranks_gloo(tmp_path):
     assert out["config"]["global_batch"] == 4 and out["config"]["frames_per_gpu_per_step"] == 2
     # value = frames of ALL ranks / max-over-ranks time
     assert abs(out["value"] - 2 * 2 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3
-    # DDP: both ranks hold the same (averaged) gradients although they saw different batches
+    # both ranks hold the same (averaged) gradients although they saw different batches
     fps = [float(open(os.path.join(tmp_path, "rank%d.txt" % r)).read()) for r in range(2)]
     assert fps[0] > 0 and abs(fps[0] - fps[1]) <= 1e-9 * abs(fps[0])
+    assert "flat all-reduce" in out["config"]["parallelism"]
+    # the flat per-dtype all-reduce (bevfusion_amd/grad_sync.py) and torch DDP produce the same averaged gradients
+    out_ddp = _run(2, tmp_path, grad_sync="ddp")
+    assert "DDP" in out_ddp["config"]["parallelism"]
+    fps_ddp = [float(open(os.path.join(tmp_path, "rank%d.txt" % r)).read()) for r in range(2)]
+    assert abs(fps_ddp[0] - fps_ddp[1]) <= 1e-9 * abs(fps_ddp[0])
+    assert abs(fps_ddp[0] - fps[0]) <= 1e-5 * abs(fps[0])
 
 
 def test_single_rank_json_contract(tmp_path):
@@ -51,3 +59,28 @@ def test_single_rank_json_contract(tmp_path):
                 "vs_baseline", "dtype", "data", "config"):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["vs_baseline"] is None
+
+
+def test_flat_grad_allreduce_handles_missing_grads_single_process(tmp_path):
+    """FlatGradAllReduce on a 1-rank gloo group: gradients survive the round trip unchanged, a parameter without a gradient
+    gets zeros, mixed dtypes go through separate flat buffers."""
+    code = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bevfusion_amd
+from bevfusion_amd.grad_sync import FlatGradAllReduce, broadcast_parameters
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
+dist.init_process_group("gloo", rank=0, world_size=1)
+a = torch.nn.Parameter(torch.randn(3, 4)); b = torch.nn.Parameter(torch.randn(5).to(torch.bfloat16)); c = torch.nn.Parameter(torch.randn(2))
+m = torch.nn.ParameterList([a, b, c])
+broadcast_parameters(m)
+(a.sum() * 2 + b.float().sum() * 3).backward()
+ga, gb = a.grad.clone(), b.grad.clone()
+gs = FlatGradAllReduce(m.parameters())
+assert len(gs.groups) == 2 and gs.bytes_per_step() == (12 + 2) * 4 + 5 * 2
+gs.reduce()
+assert torch.equal(a.grad, ga) and torch.equal(b.grad, gb) and c.grad is not None and float(c.grad.abs().sum()) == 0.0
+print("ok")
+""" % (ROOT, _free_port())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
