@@ -187,7 +187,6 @@ class _ModelWorkload:
         torch.backends.cudnn.benchmark = MIOPEN_FIND               # MIOpen exhaustive find (minutes of warm-up on a fresh box)
         self.n_params = sum(p.numel() for p in self.model.parameters())
         self.step_model = self.model
-        self._graph_trunk = self.camera and os.environ.get("BENCH_GRAPH_TRUNK", "0") == "1"
         self.master_weights = self.amp and os.environ.get("BENCH_MASTER_WEIGHTS", "1") == "1"
         if self.master_weights:
             # conv / linear weights held in bf16 (what the kernels consume), fp32 masters in the optimizer: same arithmetic
@@ -224,12 +223,6 @@ class _ModelWorkload:
                 self.inputs[dst] = torch.from_numpy(rig[src]).to(device)
         self.nk = self.m = None
         self._layer_stats = None
-        if self._graph_trunk:
-            # a few eager steps first (MIOpen solver selection, workspace growth), then capture the image trunk
-            for _ in range(2):
-                self.step()
-            torch.cuda.synchronize()
-            self.model.graph_image_trunk(self.inputs["imgs"], torch.bfloat16 if self.amp else None)
 
     def step(self):
         self.opt.zero_grad() if self.master_weights else self.opt.zero_grad(set_to_none=True)

@@ -113,13 +113,10 @@ class BEVFusion(nn.Module):
     def extract_img_feat(self, x, points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
                          lidar_aug_matrix, img_metas=None, geom_feats=None):
         B, N, C, H, W = x.size()
-        if getattr(self, "_img_trunk_graphed", None) is not None and self.training:
-            x = self._img_trunk_graphed(x.reshape(B * N, C, H, W))
-        else:
-            x = self.img_backbone(x.reshape(B * N, C, H, W))
-            x = self.img_neck(x)
-            if not isinstance(x, torch.Tensor):
-                x = x[0]
+        x = self.img_backbone(x.reshape(B * N, C, H, W))
+        x = self.img_neck(x)
+        if not isinstance(x, torch.Tensor):
+            x = x[0]
         BN, C, H, W = x.size()
         x = x.reshape(B, N, C, H, W)
         # the view transform's conv stacks run in its own autocast (conv_dtype); when that is on, the bf16 features go in
@@ -128,29 +125,6 @@ class BEVFusion(nn.Module):
         with torch.autocast("cuda", enabled=False):  # fp32 island, as the reference (:177)
             return self.view_transform(x if keep else x.float(), points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
                                        lidar_aug_matrix, img_metas, geom_feats_precomputed=geom_feats)
-
-    def graph_image_trunk(self, sample_imgs, autocast_dtype=None):
-        """Capture forward + backward of the static-shape image trunk (backbone + neck, ~40 % of the step's kernel launches)
-        into HIP graphs (torch.cuda.make_graphed_callables): replays cost one launch each instead of ~900 host-side op
-        dispatches.  `sample_imgs` [B, N, 3, H, W] fixes the shape; call before wrapping the model in DDP."""
-        model = self
-
-        class _Trunk(nn.Module):
-            def __init__(self):
-                super().__init__()
-                self.backbone, self.neck = model.img_backbone, model.img_neck
-
-            def forward(self, x):
-                x = self.neck(self.backbone(x))
-                return x if isinstance(x, torch.Tensor) else x[0]
-
-        B, N, C, H, W = sample_imgs.shape
-        sample = sample_imgs.reshape(B * N, C, H, W).detach().clone()
-        with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None,
-                            cache_enabled=False):
-            graphed = torch.cuda.make_graphed_callables(_Trunk(), (sample,))
-        object.__setattr__(self, "_img_trunk_graphed", graphed)  # not a registered submodule: parameters stay where they are
-        return graphed
 
     def extract_feat(self, batch_inputs_dict: Dict, batch_input_metas=None):
         imgs = batch_inputs_dict.get("imgs", None)
