@@ -210,3 +210,30 @@ def gt_boxes(seed=3000, n=None, point_cloud_range=NUSC["point_cloud_range"]):
     yaw = rs.uniform(-np.pi, np.pi, (g, 1)).astype(np.float32)
     vel = (rs.normal(0, 2.0, (g, 2)) * (rs.uniform(0, 1, (g, 1)) < 0.4)).astype(np.float32)
     return np.concatenate([xy, z, size, yaw, vel], 1).astype(np.float32), labels
+
+
+def bev_pool_case(seed, n, C, B, D, H, W, integer):
+    """Seeded sorted bev_pool inputs with a long-tailed interval-length distribution (numpy PCG64: stable across boxes).
+    Returns x f32[n, C], geom i32[n, 4] (x, y, z, b), ranks i64[n] (depth_lss.py:165-170 rank formula), sorted by rank."""
+    rng = np.random.default_rng(seed)
+    cells = B * D * H * W
+    lengths = []
+    while sum(lengths) < n:
+        r = rng.random()
+        ln = int(rng.geometric(1 / 14.0)) if r < 0.97 else int(rng.integers(200, 900))
+        lengths.append(ln)
+    lengths[-1] -= sum(lengths) - n
+    m = len(lengths)
+    assert m <= cells
+    cell_ids = np.sort(rng.choice(cells, m, replace=False))
+    rank = np.repeat(cell_ids, lengths).astype(np.int64)
+    # rank = x*(W*D*B) + y*(D*B) + z*B + b   with nx = (H, W, D) in the reference's naming (x <-> H axis)
+    xs, rem = rank // (W * D * B), rank % (W * D * B)
+    ys, rem = rem // (D * B), rem % (D * B)
+    zs, bs = rem // B, rem % B
+    geom = np.stack([xs, ys, zs, bs], 1).astype(np.int32)
+    if integer:
+        x = rng.integers(-8, 9, (n, C)).astype(np.float32)
+    else:
+        x = rng.standard_normal((n, C)).astype(np.float32)
+    return x, geom, rank

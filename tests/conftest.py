@@ -26,6 +26,12 @@ def golden_lss():
 
 
 @pytest.fixture(scope="session")
+def golden_bev():
+    """Outputs of the reference's own QuickCumsum (fp64) + interval tables (tests/golden/make_golden.py section D)."""
+    return np.load(os.path.join(GOLDEN, "bev_pool_ref.npz"))
+
+
+@pytest.fixture(scope="session")
 def dev():
     import torch
     if not torch.cuda.is_available():

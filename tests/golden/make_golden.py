@@ -330,10 +330,82 @@ def make_head_goldens():
     print("head_ref.npz:", {k: getattr(val, "shape", val) for k, val in out.items()})
 
 
+# --------------------------------------------------------------------------------------- (D)
+def load_reference_bev_pool():
+    """(D) projects/BEVFusion/bevfusion/ops/bev_pool/bev_pool.py loaded BY PATH.  Its line 4 (`from . import bev_pool_ext`,
+    the CUDA-only pybind module) is satisfied by a recording placeholder: `bev_pool_forward` / `bev_pool_backward` store
+    the arguments the reference's python hands to its kernel and return zeros.  `QuickCumsum` (bev_pool.py:7-34), the
+    reference's only CPU-capable formulation of the pooled sum, is pure torch and runs as is."""
+    rec = {}
+    ext = types.ModuleType("refbevpool.bev_pool_ext")
+
+    def bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, B, D, H, W):
+        rec.update(fwd_lengths=interval_lengths.clone(), fwd_starts=interval_starts.clone(), fwd_geom=geom_feats.clone())
+        return x.new_zeros((B, D, H, W, x.shape[1]))
+
+    def bev_pool_backward(out_grad, geom_feats, interval_lengths, interval_starts, B, D, H, W):
+        rec.update(bwd_lengths=interval_lengths.clone(), bwd_starts=interval_starts.clone())
+        return out_grad.new_zeros((geom_feats.shape[0], out_grad.shape[-1]))
+
+    ext.bev_pool_forward, ext.bev_pool_backward = bev_pool_forward, bev_pool_backward
+    pkg = types.ModuleType("refbevpool")
+    pkg.__path__ = []
+    pkg.bev_pool_ext = ext
+    sys.modules["refbevpool"] = pkg
+    sys.modules["refbevpool.bev_pool_ext"] = ext
+    path = os.path.join(REF, "projects/BEVFusion/bevfusion/ops/bev_pool/bev_pool.py")
+    spec = importlib.util.spec_from_file_location("refbevpool.bev_pool", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["refbevpool.bev_pool"] = mod
+    spec.loader.exec_module(mod)
+    return mod, rec
+
+
+def make_bev_pool_goldens():
+    """Outputs of the REFERENCE's own `QuickCumsum` (evaluated in fp64, where its prefix-sum cancellation is exact to
+    ~1e-16) and the interval tables its `QuickCumsumTrainingCuda` hands to the kernel."""
+    mod, rec = load_reference_bev_pool()
+    out = {}
+    for name, (seed, n, C, B, D, H, W, integer) in dict(
+            int=(41, 24000, 80, 2, 1, 32, 32, True), flt=(42, 40000, 80, 2, 1, 48, 48, False),
+            odd=(43, 5000, 8, 1, 2, 16, 16, False)).items():
+        x, geom, ranks = synthetic.bev_pool_case(seed, n, C, B, D, H, W, integer)
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        y, g = mod.QuickCumsum.apply(xt, torch.from_numpy(geom), torch.from_numpy(ranks))
+        # dense [B, D, H, W, C] exactly as the reference's LSS code scatters QuickCumsum's rows (depth_lss.py bev_pool
+        # with QuickCumsum: final[geom[:,3], :, geom[:,2], geom[:,0], geom[:,1]] = x)
+        dense = torch.zeros(B, D, H, W, C, dtype=torch.float64)
+        gl = g.long()
+        dense[gl[:, 3], gl[:, 2], gl[:, 0], gl[:, 1]] = y.detach()
+        wrng = np.random.default_rng(seed + 1000)
+        gy = torch.from_numpy(wrng.integers(-4, 5, tuple(y.shape)).astype(np.float64))
+        y.backward(gy)
+        xg = xt.grad.numpy()
+        # the reference's interval construction (bev_pool.py:48-54) as handed to its kernel
+        mod.QuickCumsumTrainingCuda.apply(torch.from_numpy(x), torch.from_numpy(geom), torch.from_numpy(ranks), B, D, H, W)
+        dense_grad = torch.zeros(B, D, H, W, C, dtype=torch.float64)
+        dense_grad[gl[:, 3], gl[:, 2], gl[:, 0], gl[:, 1]] = gy
+        out.update({f"{name}_cfg": np.array([seed, n, C, B, D, H, W, int(integer)], np.int64),
+                    f"{name}_x_sha": sha(x), f"{name}_geom_sha": sha(geom), f"{name}_ranks_sha": sha(ranks),
+                    f"{name}_rows": y.detach().numpy().astype(np.float64 if not integer else np.float32),
+                    f"{name}_row_geom": g.numpy().astype(np.int32),
+                    f"{name}_starts": rec["fwd_starts"].numpy(), f"{name}_lengths": rec["fwd_lengths"].numpy(),
+                    f"{name}_dense_sha_f32": sha(dense.numpy().astype(np.float32)),
+                    f"{name}_grad_rows": gy.numpy().astype(np.float32),
+                    f"{name}_xgrad_sha_f32": sha(xg.astype(np.float32)),
+                    f"{name}_xgrad_sample": xg.astype(np.float32)[::211].copy()})
+    np.savez_compressed(os.path.join(HERE, "bev_pool_ref.npz"), **out)
+    print("bev_pool_ref.npz:", {k: getattr(val, "shape", val) for k, val in out.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "head":
         make_head_goldens()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bev_pool":
+        make_bev_pool_goldens()
+        sys.exit(0)
     make_voxel_goldens()
     make_lss_goldens()
     make_head_goldens()
+    make_bev_pool_goldens()

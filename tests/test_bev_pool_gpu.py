@@ -139,3 +139,35 @@ def test_full_size_properties(dev):
     # backward: every row receives its cell's gradient -> idempotent under fwd(bwd(.)) scaling by length
     xg = bev_pool_ext.bev_pool_backward(o1, G, L, S, b, d, h, w, _cover_all=True)
     assert torch.equal(xg[S.long()], o1[0, 0, G[S.long(), 0].long(), G[S.long(), 1].long()])
+
+
+@pytest.mark.parametrize("name", ["int", "flt", "odd"])
+def test_vs_reference_quickcumsum_golden(dev, golden_bev, name):
+    """HIP op through the C ABI against the outputs of the REFERENCE's own QuickCumsum (bev_pool.py:7-34, fp64) and its
+    interval construction (:48-54): tests/golden/bev_pool_ref.npz."""
+    from bevfusion_amd import synthetic
+    from util import sha
+    seed, n, C, B, D, H, W, integer = [int(v) for v in golden_bev[name + "_cfg"]]
+    x, geom, ranks = synthetic.bev_pool_case(seed, n, C, B, D, H, W, bool(integer))
+    assert sha(x) == str(golden_bev[name + "_x_sha"]) and sha(ranks) == str(golden_bev[name + "_ranks_sha"])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    s_dev, l_dev = intervals_from_ranks(t(ranks))
+    assert np.array_equal(s_dev.cpu().numpy(), golden_bev[name + "_starts"])
+    assert np.array_equal(l_dev.cpu().numpy(), golden_bev[name + "_lengths"])
+    out = bev_pool_ext.bev_pool_forward(t(x), t(geom), l_dev, s_dev, B, D, H, W).cpu().numpy()
+    rg = golden_bev[name + "_row_geom"]
+    rows = out[rg[:, 3], rg[:, 2], rg[:, 0], rg[:, 1]]
+    want = golden_bev[name + "_rows"]
+    if integer:
+        assert np.array_equal(rows, want) and sha(out) == str(golden_bev[name + "_dense_sha_f32"])
+    else:
+        lengths = golden_bev[name + "_lengths"]
+        assert np.abs(rows - want).max() <= 1e-6 * np.abs(want).max() * np.sqrt(lengths.max())
+    og = np.zeros((B, D, H, W, C), np.float32)
+    og[rg[:, 3], rg[:, 2], rg[:, 0], rg[:, 1]] = golden_bev[name + "_grad_rows"]
+    xg = bev_pool_ext.bev_pool_backward(t(og), t(geom), l_dev, s_dev, B, D, H, W).cpu().numpy()
+    assert sha(xg) == str(golden_bev[name + "_xgrad_sha_f32"])
+    # python op (autograd path) too
+    feats = t(x).requires_grad_(True)
+    o = bev_pool(feats, t(geom).long(), t(ranks), B, D, H, W, True)
+    assert np.array_equal(o.detach().permute(0, 2, 3, 4, 1).cpu().numpy(), out)

@@ -290,3 +290,39 @@ def test_depth_histogram_bit_exact_vs_reference(golden_lss):
     counts, distr = oracle.depth_histogram(ref.reshape(12, 64, 176), 8, 22, 20, [1.0, 61.0, 3.0])
     assert np.array_equal(counts.reshape(2, 6, 8, 22, 20), golden_lss["rast_counts"])
     assert np.array_equal(distr.reshape(2, 6, 8, 22, 20), golden_lss["rast_gt_distr"])
+
+
+# ------------------------------------------------------------------ bev_pool vs the reference's own QuickCumsum
+def _bev_case(golden_bev, name):
+    seed, n, C, B, D, H, W, integer = [int(v) for v in golden_bev[name + "_cfg"]]
+    x, geom, ranks = synthetic.bev_pool_case(seed, n, C, B, D, H, W, bool(integer))
+    assert sha(x) == str(golden_bev[name + "_x_sha"]) and sha(geom) == str(golden_bev[name + "_geom_sha"])
+    assert sha(ranks) == str(golden_bev[name + "_ranks_sha"]), "synthetic input drifted from the golden's"
+    return x, geom, ranks, (B, D, H, W, C)
+
+
+@pytest.mark.parametrize("name", ["int", "flt", "odd"])
+def test_bev_pool_vs_reference_quickcumsum(golden_bev, name):
+    """The oracle's bev_pool sum, interval tables and backward against the outputs of the REFERENCE's QuickCumsum
+    (BF/ops/bev_pool/bev_pool.py:7-34, run in fp64) and of its interval construction (:48-54).  Integer-valued inputs:
+    bit-exact; normal inputs: <= 1e-6 of the row scale (fp32 serial sum vs the exact fp64 sum)."""
+    x, geom, ranks, (B, D, H, W, C) = _bev_case(golden_bev, name)
+    starts, lengths = oracle.intervals_from_ranks(ranks)
+    assert np.array_equal(starts, golden_bev[name + "_starts"]) and np.array_equal(lengths, golden_bev[name + "_lengths"])
+    out = oracle.bev_pool_fwd(x, geom, starts, lengths, B, D, H, W)
+    rg = golden_bev[name + "_row_geom"]
+    assert np.array_equal(rg, geom[starts + lengths - 1])          # QuickCumsum keeps the LAST row of each rank
+    rows = out[rg[:, 3], rg[:, 2], rg[:, 0], rg[:, 1]]
+    want = golden_bev[name + "_rows"]
+    if name == "int":
+        assert np.array_equal(rows, want) and sha(out) == str(golden_bev[name + "_dense_sha_f32"])
+    else:
+        scale = np.abs(want).max()
+        assert np.abs(rows - want).max() <= 1e-6 * scale * np.sqrt(lengths.max())
+    assert np.count_nonzero(out) <= rows.size
+    # backward: every member row of an interval receives its cell's gradient (QuickCumsum.backward: gradx[back])
+    og = np.zeros((B, D, H, W, C), np.float32)
+    og[rg[:, 3], rg[:, 2], rg[:, 0], rg[:, 1]] = golden_bev[name + "_grad_rows"]
+    xg = oracle.bev_pool_bwd(og, geom, starts, lengths, x.shape[0])
+    assert sha(xg) == str(golden_bev[name + "_xgrad_sha_f32"])
+    assert np.array_equal(xg[::211], golden_bev[name + "_xgrad_sample"])
