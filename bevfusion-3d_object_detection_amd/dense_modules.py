@@ -116,15 +116,46 @@ def upsample_to(x, size, cfg):
     return F.interpolate(x, size=size, **cfg)
 
 
-def _conv_module(cin, cout, k, padding=0, norm=True, act=True, eps=1e-5, momentum=0.1, stride=1):
-    layers = [nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=not norm)]
-    if norm and act:
-        layers += bn_act(cout, eps=eps, momentum=momentum)
-    elif norm:
-        layers.append(BatchNorm2dAct(cout, eps=eps, momentum=momentum))
-    elif act:
-        layers.append(nn.ReLU(inplace=True))
-    return nn.Sequential(*layers)
+class ConvModule(nn.Module):
+    """The subset of mmcv's ConvModule the reference uses: conv -> (BatchNorm) -> (ReLU) with the children named `conv` and
+    `bn`, so that state-dict keys are the reference's (`<name>.conv.weight`, `<name>.bn.weight`, ...;
+    BF/bevfusion_necks.py:50-72, BF/bevfusion_head.py:104-115, centerpoint_head.py:60-70).  `bias='auto'` = no bias when a
+    norm follows.  2-D modules fuse BN + ReLU (csrc/bn2d.hip); `dim=1` builds the Conv1d / BatchNorm1d form."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, norm=True, act=True, bias="auto", eps=1e-5, momentum=0.1, dim=2):
+        super().__init__()
+        bias = (not norm) if bias == "auto" else bool(bias)
+        if dim == 2:
+            self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=bias)
+            self.bn = BatchNorm2dAct(cout, eps=eps, momentum=momentum, act=act) if norm else None
+        else:
+            self.conv = nn.Conv1d(cin, cout, k, stride=stride, padding=padding, bias=bias)
+            self.bn = nn.BatchNorm1d(cout, eps=eps, momentum=momentum) if norm else None
+        self.dim, self.act = dim, act
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is None:
+            return F.relu(x) if self.act else x
+        if self.dim == 2:
+            return self.bn(x)          # BatchNorm2dAct applies the ReLU itself
+        x = self.bn(x)
+        return F.relu(x) if self.act else x
+
+
+class FFN(nn.Module):
+    """mmcv FFN (num_fcs = 2, add_identity): `layers` = Sequential(Sequential(Linear, ReLU, Dropout), Linear, Dropout);
+    keys `layers.0.0.weight`, `layers.1.weight` as in the reference's checkpoints (BF/transformer.py:26 builds it through
+    mmdet's DetrTransformerDecoderLayer)."""
+
+    def __init__(self, embed_dims, feedforward_channels, ffn_drop=0.0):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)),
+            nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop))
+
+    def forward(self, x):
+        return x + self.layers(x)
 
 
 @MODELS.register_module()
@@ -144,8 +175,8 @@ class GeneralizedLSSFPN(nn.Module):
         self.lateral_convs, self.fpn_convs = nn.ModuleList(), nn.ModuleList()
         for i in range(start_level, self.backbone_end_level):
             cin = in_channels[i] + (in_channels[i + 1] if i == self.backbone_end_level - 1 else out_channels)
-            self.lateral_convs.append(_conv_module(cin, out_channels, 1, norm=not no_norm_on_lateral))
-            self.fpn_convs.append(_conv_module(out_channels, out_channels, 3, padding=1))
+            self.lateral_convs.append(ConvModule(cin, out_channels, 1, norm=not no_norm_on_lateral))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1))
 
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
@@ -294,8 +325,7 @@ class TransformerDecoderLayer(nn.Module):
         self.self_attn = _MHA(d, self_attn_cfg["num_heads"], self_attn_cfg.get("dropout", 0.0))
         self.cross_attn = _MHA(d, cross_attn_cfg["num_heads"], cross_attn_cfg.get("dropout", 0.0))
         ff, drop = ffn_cfg["feedforward_channels"], ffn_cfg.get("ffn_drop", 0.0)
-        self.ffn = nn.Sequential(nn.Linear(d, ff), nn.ReLU(inplace=True), nn.Dropout(drop), nn.Linear(ff, d),
-                                 nn.Dropout(drop))
+        self.ffn = FFN(d, ff, drop)
         self.norms = nn.ModuleList([nn.LayerNorm(d) for _ in range(3)])
         self.self_posembed = PositionEncodingLearned(**pos_encoding_cfg)
         self.cross_posembed = PositionEncodingLearned(**pos_encoding_cfg)
@@ -307,7 +337,7 @@ class TransformerDecoderLayer(nn.Module):
         q, k = query.transpose(1, 2), key.transpose(1, 2)
         q = self.norms[0](self.self_attn(q, q, q + qp, qp, qp))
         q = self.norms[1](self.cross_attn(q, k, k + kp, qp, kp))
-        q = self.norms[2](q + self.ffn(q))
+        q = self.norms[2](self.ffn(q))
         return q.transpose(1, 2)
 
 
@@ -318,8 +348,7 @@ class SeparateHead(nn.Module):
         for head, (classes, num_conv) in heads.items():
             layers, c_in = [], in_channels
             for _ in range(num_conv - 1):
-                layers += [nn.Conv1d(c_in, head_conv, final_kernel, padding=final_kernel // 2, bias=False),
-                           nn.BatchNorm1d(head_conv), nn.ReLU(inplace=True)]
+                layers.append(ConvModule(c_in, head_conv, final_kernel, padding=final_kernel // 2, dim=1))
                 c_in = head_conv
             layers.append(nn.Conv1d(head_conv, classes, final_kernel, padding=final_kernel // 2, bias=True))
             self.add_module(head, nn.Sequential(*layers))
@@ -358,9 +387,8 @@ class BEVFusionHead(nn.Module):
         self.num_classes, self.num_proposals = num_classes, num_proposals
         self.num_decoder_layers, self.nms_kernel_size, self.auxiliary = num_decoder_layers, nms_kernel_size, auxiliary
         self.shared_conv = nn.Conv2d(in_channels, hidden_channel, 3, padding=1)
-        self.heatmap_head = nn.Sequential(
-            nn.Conv2d(hidden_channel, hidden_channel, 3, padding=1, bias=False), *bn_act(hidden_channel),
-            nn.Conv2d(hidden_channel, num_classes, 3, padding=1))
+        self.heatmap_head = nn.Sequential(ConvModule(hidden_channel, hidden_channel, 3, padding=1),
+                                          nn.Conv2d(hidden_channel, num_classes, 3, padding=1))
         self.class_encoding = nn.Conv1d(num_classes, hidden_channel, 1)
         self.decoder = nn.ModuleList([TransformerDecoderLayer(**decoder_layer) for _ in range(num_decoder_layers)])
         heads = dict(common_heads)
@@ -426,16 +454,21 @@ class BEVFusionHead(nn.Module):
         P = self.num_proposals
         L = self.num_decoder_layers if self.auxiliary else 1
         vel = preds_dict.get("vel")
-        outs = []
+        outs, statuses = [], []
         for layer in range(L):
             boxes = self.bbox_coder.decode_boxes(preds_dict["rot"], preds_dict["dim"], preds_dict["center"],
                                                  preds_dict["height"], vel, p_off=layer * P, num=P)
-            assigned, iou, _, _ = ht.assign_batch(boxes, preds_dict["heatmap"], gt_boxes, gt_labels, n_gt,
-                                                  tc["point_cloud_range"], self.assign_weights, p_off=layer * P)
+            assigned, iou, _, status = ht.assign_batch(boxes, preds_dict["heatmap"], gt_boxes, gt_labels, n_gt,
+                                                       tc["point_cloud_range"], self.assign_weights, p_off=layer * P)
+            statuses.append(status)
             outs.append(ht.build_targets(assigned, iou, gt_boxes, gt_labels, self.num_classes, self.bbox_coder.code_size,
                                          tc["point_cloud_range"], tc["out_size_factor"], tc["voxel_size"],
                                          tc.get("pos_weight", -1)))
         labels, label_weights, bbox_targets, bbox_weights, ious = [torch.cat(x, dim=1) if L > 1 else x[0] for x in zip(*outs)]
+        # status != 0: a NaN / inf matching cost (scipy's linear_sum_assignment raises "matrix contains invalid numeric
+        # entries" there, BF/utils.py:270).  Kept on the device and folded into the losses as NaN by loss_by_feat, so the
+        # failure is visible without a per-step host read; `assignment_status` is there for callers that want to raise.
+        self.assignment_status = torch.stack(statuses) if L > 1 else statuses[0]
         pos_per_sample = [min(c, P) * L for c in counts]  # the Hungarian step matches min(#GT, #proposals) pairs
         num_pos = sum(pos_per_sample)
         denom = torch.tensor([max(n, 1) for n in pos_per_sample], dtype=torch.float32).to(dev, non_blocking=True)
@@ -471,7 +504,19 @@ class BEVFusionHead(nn.Module):
             loss_dict[f"{prefix}_loss_cls"] = cls_sum / avg * self.loss_cls_cfg.get("loss_weight", 1.0)
             loss_dict[f"{prefix}_loss_bbox"] = box_sum / avg * self.loss_bbox_cfg.get("loss_weight", 1.0)
         loss_dict["matched_ious"] = matched_ious
+        # an invalid matching cost (NaN / inf) leaves every query unmatched: poison the losses instead of training on
+        # background-only targets with the wrong normaliser (the reference raises from scipy at this point)
+        poison = torch.where(self.assignment_status.ne(0).any(), float("nan"), 0.0)
+        for k in loss_dict:
+            if "loss" in k:
+                loss_dict[k] = loss_dict[k] + poison
         return loss_dict
+
+    def check_assignment(self):
+        """Host-side check of the last get_targets() (one device read): raises like scipy's linear_sum_assignment does on
+        a cost matrix with invalid entries (BF/utils.py:267-270)."""
+        if getattr(self, "assignment_status", None) is not None and bool(self.assignment_status.ne(0).any()):
+            raise ValueError("matrix contains invalid numeric entries")
 
     def loss(self, batch_feats, batch_data_samples):
         """BF/bevfusion_head.py:676-694.  `batch_data_samples`: objects with `.gt_instances_3d` (+ `.metainfo`), or the

@@ -1,0 +1,277 @@
+"""Module-level parity of the dense rows of SURVEY 8(a) -- a-8 ConvFuser, a-9 SECOND / SECONDFPN, a-10 head convs,
+a-11 view-transform conv stacks and GeneralizedLSSFPN -- against PLAIN torch.nn twins (nn.Conv2d + nn.BatchNorm2d +
+nn.ReLU, written here from the reference's layer lists) evaluated in fp32 on the CPU with the same weights.
+
+The twins load the product modules' state dicts with strict=True, so the tests also pin the state-dict layout to the
+reference's (`nn.Sequential` indices / mmcv ConvModule child names).
+
+CPU tests (not gpu): the product module on the CPU equals its twin (host logic, key layout).
+GPU tests: the product module on the MI355X (fused BN kernels, hand-written / library convs, channels-last) against the
+twin: forward, input gradient and every parameter gradient; <= 1e-3 rel in fp32, <= 1e-2 rel under bf16 autocast
+(north_star tolerances; relative = max |a - b| / max |b| for fp32, relative L2 for bf16).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+import bevfusion_amd  # noqa: F401
+from bevfusion_amd import dense_modules as dm
+from bevfusion_amd import depth_lss
+
+
+# ------------------------------------------------------------------ plain torch.nn twins (reference layer lists)
+def cbr(cin, cout, k, s=1, p=0, eps=1e-5, mom=0.1, bias=False):
+    return [nn.Conv2d(cin, cout, k, stride=s, padding=p, bias=bias), nn.BatchNorm2d(cout, eps=eps, momentum=mom), nn.ReLU()]
+
+
+class PlainConvModule(nn.Module):  # mmcv ConvModule: conv -> bn -> relu, children `conv`, `bn`
+    def __init__(self, cin, cout, k, p=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=p, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)))
+
+
+class PlainConvFuser(nn.Sequential):  # BF/bevfusion_head.py:26-38
+    def __init__(self, cin, cout):
+        super().__init__(*cbr(sum(cin), cout, 3, p=1))
+
+    def forward(self, inputs):
+        return super().forward(torch.cat(inputs, dim=1))
+
+
+class PlainSECOND(nn.Module):  # mmdet3d/models/backbones/second.py:27-95
+    def __init__(self, cin, couts, nums, strides, eps=1e-3, mom=0.01):
+        super().__init__()
+        chans = [cin, *couts[:-1]]
+        self.blocks = nn.ModuleList()
+        for i, n in enumerate(nums):
+            layers = cbr(chans[i], couts[i], 3, s=strides[i], p=1, eps=eps, mom=mom)
+            for _ in range(n):
+                layers += cbr(couts[i], couts[i], 3, p=1, eps=eps, mom=mom)
+            self.blocks.append(nn.Sequential(*layers))
+
+    def forward(self, x):
+        outs = []
+        for b in self.blocks:
+            x = b(x)
+            outs.append(x)
+        return tuple(outs)
+
+
+class PlainSECONDFPN(nn.Module):  # mmdet3d/models/necks/second_fpn.py:30-94 (use_conv_for_no_stride=True, strides 1, 2)
+    def __init__(self, cins, couts, strides, eps=1e-3, mom=0.01):
+        super().__init__()
+        self.deblocks = nn.ModuleList()
+        for c, o, s in zip(cins, couts, strides):
+            up = nn.ConvTranspose2d(c, o, s, stride=s, bias=False) if s > 1 else nn.Conv2d(c, o, 1, stride=1, bias=False)
+            self.deblocks.append(nn.Sequential(up, nn.BatchNorm2d(o, eps=eps, momentum=mom), nn.ReLU()))
+
+    def forward(self, xs):
+        return [torch.cat([d(x) for d, x in zip(self.deblocks, xs)], dim=1)]
+
+
+class PlainLSSFPN(nn.Module):  # BF/bevfusion_necks.py:11-96
+    def __init__(self, cins, cout):
+        super().__init__()
+        self.lateral_convs, self.fpn_convs = nn.ModuleList(), nn.ModuleList()
+        n = len(cins) - 1
+        for i in range(n):
+            self.lateral_convs.append(PlainConvModule(cins[i] + (cins[i + 1] if i == n - 1 else cout), cout, 1))
+            self.fpn_convs.append(PlainConvModule(cout, cout, 3, p=1))
+
+    def forward(self, inputs):
+        lat = list(inputs)
+        for i in range(len(lat) - 2, -1, -1):
+            x = F.interpolate(lat[i + 1], size=lat[i].shape[2:], mode="bilinear", align_corners=False)
+            lat[i] = self.fpn_convs[i](self.lateral_convs[i](torch.cat([lat[i], x], dim=1)))
+        return tuple(lat[:-1])
+
+
+class PlainHeadConvs(nn.Module):  # BF/bevfusion_head.py:95-126, forward :207,220
+    def __init__(self, cin, hidden, classes):
+        super().__init__()
+        self.shared_conv = nn.Conv2d(cin, hidden, 3, padding=1)
+        self.heatmap_head = nn.Sequential(PlainConvModule(hidden, hidden, 3, p=1), nn.Conv2d(hidden, classes, 3, padding=1))
+
+    def forward(self, x):
+        f = self.shared_conv(x)
+        return f, self.heatmap_head(f)
+
+
+def plain_dtransform():  # BF/depth_lss.py:581-591
+    return nn.Sequential(*cbr(1, 8, 1, bias=True), *cbr(8, 32, 5, s=4, p=2, bias=True), *cbr(32, 64, 5, s=2, p=2, bias=True))
+
+
+def plain_depthnet(cin, d_plus_c):  # BF/depth_lss.py:592-600
+    return nn.Sequential(*cbr(cin + 64, cin, 3, p=1, bias=True), *cbr(cin, cin, 3, p=1, bias=True), nn.Conv2d(cin, d_plus_c, 1))
+
+
+def plain_downsample(c):  # BF/depth_lss.py:601-620
+    return nn.Sequential(*cbr(c, c, 3, p=1), *cbr(c, c, 3, s=2, p=1), *cbr(c, c, 3, p=1))
+
+
+# ------------------------------------------------------------------ cases: (product module, twin, inputs, call)
+class _HeadConvs(nn.Module):
+    """shared_conv + heatmap_head of the product head, called as forward_single does (:207, :218-220: fp32 heat-map)."""
+
+    def __init__(self, cin, hidden, classes):
+        super().__init__()
+        self.shared_conv = nn.Conv2d(cin, hidden, 3, padding=1)
+        self.heatmap_head = nn.Sequential(dm.ConvModule(hidden, hidden, 3, padding=1), nn.Conv2d(hidden, classes, 3, padding=1))
+
+    def forward(self, x):
+        f = self.shared_conv(x)
+        with torch.autocast("cuda", enabled=False):
+            return f, self.heatmap_head(f.float())
+
+
+def _randn(*shape, seed=0):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape).astype(np.float32))
+
+
+def _cases():
+    H, W = 45, 52  # odd sizes: partial tiles in every hand-written kernel
+    c = {}
+    c["ConvFuser"] = (lambda: dm.ConvFuser([80, 256], 256), lambda: PlainConvFuser([80, 256], 256),
+                      lambda: ([_randn(2, 80, H, W, seed=1), _randn(2, 256, H, W, seed=2)],))
+    c["SECOND"] = (lambda: dm.SECOND(256, [128, 256], [5, 5], [1, 2], norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01)),
+                   lambda: PlainSECOND(256, [128, 256], [5, 5], [1, 2]), lambda: (_randn(2, 256, 44, 52, seed=3),))
+    c["SECOND_shallow"] = (lambda: dm.SECOND(256, [128, 256], [1, 1], [1, 2], norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01)),
+                           lambda: PlainSECOND(256, [128, 256], [1, 1], [1, 2]), lambda: (_randn(2, 256, 44, 52, seed=3),))
+    c["SECONDFPN"] = (lambda: dm.SECONDFPN([128, 256], [256, 256], [1, 2], use_conv_for_no_stride=True),
+                      lambda: PlainSECONDFPN([128, 256], [256, 256], [1, 2]),
+                      lambda: ([_randn(2, 128, 44, 52, seed=4), _randn(2, 256, 22, 26, seed=5)],))
+    c["GeneralizedLSSFPN"] = (lambda: dm.GeneralizedLSSFPN([512, 1024, 2048], 256, 3, start_level=0,
+                                                           upsample_cfg=dict(mode="bilinear", align_corners=False)),
+                              lambda: PlainLSSFPN([512, 1024, 2048], 256),
+                              lambda: ([_randn(3, 512, 32, 88, seed=6), _randn(3, 1024, 16, 44, seed=7),
+                                        _randn(3, 2048, 8, 22, seed=8)],))
+    c["head_convs"] = (lambda: _HeadConvs(512, 128, 10), lambda: PlainHeadConvs(512, 128, 10),
+                       lambda: (_randn(2, 512, H, W, seed=9),))
+    c["dtransform"] = (lambda: _vt().dtransform, plain_dtransform, lambda: (_randn(3, 1, 64, 176, seed=10).abs(),))
+    c["depthnet"] = (lambda: _vt().depthnet, lambda: plain_depthnet(256, 118 + 80), lambda: (_randn(3, 320, 32, 88, seed=11),))
+    c["downsample"] = (lambda: _vt().downsample, lambda: plain_downsample(80), lambda: (_randn(2, 80, 90, 92, seed=12),))
+    return c
+
+
+def _vt():
+    return depth_lss.DepthLSSTransform(in_channels=256, out_channels=80, image_size=[256, 704], feature_size=[32, 88],
+                                       xbound=[-54.0, 54.0, 0.3], ybound=[-54.0, 54.0, 0.3], zbound=[-10.0, 10.0, 20.0],
+                                       dbound=[1.0, 60.0, 0.5], downsample=2)
+
+
+CASES = _cases()
+BF16_CASES = [k for k in CASES if k != "SECOND"]  # the 12-layer stack is checked in fp32; bf16 on its 4-layer variant
+
+
+def _flat(out):
+    if torch.is_tensor(out):
+        return [out]
+    res = []
+    for o in out:
+        res += _flat(o)
+    return res
+
+
+def _run(module, inputs, seeds, device, autocast=None):
+    def prep(t):
+        if torch.is_tensor(t):
+            t = t.to(device)
+            if device.type == "cuda" and t.dim() == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            return t.requires_grad_(True)
+        return [prep(u) for u in t]
+
+    args = [prep(a) for a in inputs]
+    leaves = _flat(args)
+    module.train()
+    if autocast is not None:
+        with torch.autocast("cuda", dtype=autocast):
+            outs = _flat(module(*args))
+    else:
+        outs = _flat(module(*args))
+    loss = sum((o.float() * s.to(device)).sum() for o, s in zip(outs, seeds))
+    loss.backward()
+    grads = {n: p.grad.detach().float().cpu() for n, p in module.named_parameters()}
+    return ([o.detach().float().cpu() for o in outs], [a.grad.detach().float().cpu() for a in leaves], grads,
+            {n: b.detach().float().cpu() for n, b in module.named_buffers() if "running" in n})
+
+
+def _build(name):
+    torch.manual_seed(1234)
+    make, make_twin, make_inputs = CASES[name]
+    mod = make()
+    for m in mod.modules():  # non-trivial affine BN parameters
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    twin = make_twin()
+    twin.load_state_dict(mod.state_dict(), strict=True)
+    inputs = make_inputs()
+    with torch.no_grad():
+        probe = _flat(copy.deepcopy(twin).train()(*copy.deepcopy(inputs)))
+    seeds = [_randn(*o.shape, seed=100 + i) / max(o.numel(), 1) ** 0.5 for i, o in enumerate(probe)]
+    return mod, twin, inputs, seeds
+
+
+def _rel_max(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _rel_l2(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _compare(got, want, tol, metric, what):
+    outs_g, gin_g, gp_g, buf_g = got
+    outs_w, gin_w, gp_w, buf_w = want
+    for i, (a, b) in enumerate(zip(outs_g, outs_w)):
+        assert a.shape == b.shape
+        assert metric(a, b) <= tol, (what, "output", i, metric(a, b))
+    for i, (a, b) in enumerate(zip(gin_g, gin_w)):
+        assert metric(a, b) <= tol, (what, "input grad", i, metric(a, b))
+    assert set(gp_g) == set(gp_w)
+    for n in gp_w:
+        if gp_w[n].abs().max() < 1e-6:   # a conv bias in front of a training-mode BN: zero gradient up to rounding
+            assert gp_g[n].abs().max() < 1e-3, (what, n)
+            continue
+        assert metric(gp_g[n], gp_w[n]) <= tol, (what, "param grad", n, metric(gp_g[n], gp_w[n]))
+    for n in buf_w:
+        assert metric(buf_g[n], buf_w[n]) <= tol, (what, "buffer", n)
+
+
+@pytest.mark.parametrize("name", ["ConvFuser", "SECOND_shallow", "SECONDFPN", "head_convs", "dtransform", "downsample"])
+def test_product_module_on_cpu_equals_plain_twin(name):
+    """Host logic: same layer list, same state-dict layout, same arithmetic when both run torch's CPU kernels."""
+    mod, twin, inputs, seeds = _build(name)
+    if name in ("ConvFuser", "head_convs"):
+        inputs = [[t[:, :, :12, :14] for t in a] if isinstance(a, list) else a[:, :, :12, :14] for a in inputs]
+        seeds = [s[:, :, :12, :14] for s in seeds]
+    cpu = torch.device("cpu")
+    _compare(_run(mod, inputs, seeds, cpu), _run(twin, inputs, seeds, cpu), 1e-5, _rel_max, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_module_fp32_vs_plain_torch_cpu(dev, name):
+    mod, twin, inputs, seeds = _build(name)
+    want = _run(twin, inputs, seeds, torch.device("cpu"))
+    got = _run(mod.to(dev), inputs, seeds, dev)
+    _compare(got, want, 1e-3, _rel_max, name + " fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BF16_CASES)
+def test_module_bf16_vs_plain_torch_cpu(dev, name):
+    mod, twin, inputs, seeds = _build(name)
+    want = _run(twin, inputs, seeds, torch.device("cpu"))
+    got = _run(mod.to(dev), inputs, seeds, dev, autocast=torch.bfloat16)
+    _compare(got, want, 1e-2, _rel_l2, name + " bf16")
