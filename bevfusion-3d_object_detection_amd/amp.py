@@ -49,8 +49,13 @@ class MasterWeightAdamW:
 
     @torch.no_grad()
     def step(self):
-        grads = [p.grad for p in self.low]
-        torch._foreach_copy_([m.grad for m in self.master], grads)  # bf16 -> fp32, one multi-tensor kernel
+        have = [(m.grad, p.grad) for m, p in zip(self.master, self.low) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([a for a, _ in have], [b for _, b in have])  # bf16 -> fp32, one multi-tensor kernel
+        if len(have) != len(self.low):
+            # a parameter unused in this step: zero gradient, as the flat all-reduce path produces at world size > 1
+            # (grad_sync.FlatGradAllReduce zero-fills), so the update does not depend on the world size
+            torch._foreach_zero_([m.grad for m, p in zip(self.master, self.low) if p.grad is None])
         if self.max_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.master + self.other, self.max_grad_norm, foreach=True)
         self.opt.step()

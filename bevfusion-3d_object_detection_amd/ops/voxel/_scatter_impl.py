@@ -8,7 +8,7 @@ _WS = {}
 
 
 def _workspace(device, nbytes, tag):
-    key = (device, tag)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)  # per stream: see spconv._workspace
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -10,14 +10,15 @@ import torch
 
 from ... import _lib
 
-_WS = {}  # (device, bytes) grow-only workspace cache; one per device
+_WS = {}  # grow-only workspace cache; one per (device, stream): see spconv._workspace
 
 
 def _workspace(device, nbytes):
-    buf = _WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 

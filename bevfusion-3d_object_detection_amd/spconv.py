@@ -27,7 +27,10 @@ _WS = {}
 
 
 def _workspace(device, nbytes, tag="ws"):
-    key = (device, tag)
+    """Grow-only scratch, one buffer per (device, current stream, tag): a buffer is only ever used by kernels of the stream
+    it was allocated under, so growing it (which frees the old one back to that stream's allocator pool) cannot hand
+    memory that side-stream kernels still use to a main-stream tensor."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -84,3 +84,61 @@ print("ok")
 """ % (ROOT, _free_port())
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+_WS4 = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bevfusion_amd
+from bevfusion_amd.grad_sync import FlatGradAllReduce
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+shapes = [((33, 7, 3, 3), torch.bfloat16), ((129,), torch.float32), ((64, 31), torch.bfloat16), ((5, 5), torch.float32)]
+def grads(r):
+    g = torch.Generator().manual_seed(100 + r)
+    return [(torch.randn(s, generator=g) * (1 + 3 * i)).to(dt) for i, (s, dt) in enumerate(shapes)]
+exact = [sum(g.double() for g in col) / world for col in zip(*[grads(r) for r in range(world)])]   # fp64 mean of what each rank holds
+res = {}
+for mode in ("a2a", "allreduce_fp32", "allreduce_bf16"):
+    ps = [torch.nn.Parameter(torch.zeros(s, dtype=dt)) for s, dt in shapes]
+    if rank == 1:
+        ps[1].requires_grad_(True)
+    for p, g in zip(ps, grads(rank)):
+        p.grad = g.clone()
+    if mode == "a2a" and rank == 2:
+        ps[3].grad = None                       # an unused parameter on one rank contributes zeros
+    gs = FlatGradAllReduce(ps, exchange=mode)
+    assert len(gs.groups) == 2
+    gs.reduce()
+    errs = []
+    for i, (p, e) in enumerate(zip(ps, exact)):
+        if mode == "a2a" and i == 3:
+            e = e - grads(2)[3].double() / world
+        errs.append(float((p.grad.double() - e).norm() / e.norm()))
+        gathered = [torch.empty_like(p.grad) for _ in range(world)]
+        dist.all_gather(gathered, p.grad)
+        assert all(torch.equal(gathered[0], t) for t in gathered), "ranks disagree"
+    res[mode] = errs
+if rank == 0:
+    print("ERRS", res)
+    for mode in ("a2a", "allreduce_fp32"):
+        assert res[mode][0] < 2.5e-3 and res[mode][2] < 2.5e-3, res      # ONE bf16 rounding of the mean (2^-9 = 1.95e-3 max rel)
+        assert res[mode][1] < 1e-6 and res[mode][3] < 1e-6, res
+    assert max(res["a2a"][0], res["a2a"][2]) <= max(res["allreduce_bf16"][0], res["allreduce_bf16"][2]) + 1e-9, res
+    print("ok")
+dist.destroy_process_group()
+"""
+
+
+def test_flat_exchange_world4_mixed_dtypes_fp32_accumulation(tmp_path):
+    """World size 4 on gloo, mixed bf16 / fp32 parameters, ragged sizes (padding of the all-to-all shards), one parameter
+    without a gradient on one rank: every rank ends with identical gradients; the bf16 group's mean is accumulated in fp32
+    (error of ONE bf16 rounding vs the fp64 mean) with both the all-to-all exchange and the widened all-reduce, and is no
+    worse than the lossy bf16-sum all-reduce."""
+    script = tmp_path / "ws4.py"
+    script.write_text(_WS4 % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
