@@ -10,9 +10,14 @@ are already resident in HBM.  Frames are independent units: every
 its own batch, there is no data-path collective, scaling is weak.  Rank 0 prints ONE JSON line.
 
 The workload registry below names what one step contains; `config.workload` in the JSON line
-says which one ran.  The roofline object is for the dominant kernel (bev_pool forward at the op
-boundary) and is measured with HIP events recorded by the library on the kernel's own stream
-(bfhip_profile_*).  cpu_baseline times the CPU oracle on a bounded sample on rank 0 at N=1.
+says which one ran.  `roofline` is for the dominant hand-written op of the workload (the one with
+the largest accumulated time: a sparse-conv op in `full` / `lidar_*`, lift_splat_fwd in
+`camera_only`, bev_pool_fwd in `hotpath_v1`); `roofline_ops` lists every hand-written op of the
+hot path with its own fraction.  Times are HIP events recorded by the library on the op's own
+stream (bfhip_profile_*).  `cpu_baseline` (rank 0, N = 1) times the reference's CPU formulation
+of the path on all host cores: C oracle voxelization, restated QuickCumsum bev_pool, the 21-layer
+sparse encoder as gather -> mm -> index_add_, and the config-0 forward of one frame
+(oracle/cpu_pipeline.py); it is a reported baseline, never the thing measured.
 """
 import argparse
 import json
@@ -41,6 +46,8 @@ MIOPEN_FIND = os.environ.get("BENCH_MIOPEN_FIND", "0") == "1"
 # gradient exchange between ranks: "flat" = one all-reduce per dtype after the backward (default), "ddp" = torch DDP buckets
 GRAD_SYNC = os.environ.get("BENCH_GRAD_SYNC", "flat")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
+# the weight-gradient kernel's MFMA type (updated when the kernel moves to the bf16 MFMA)
+WGRAD_PEAK = (157.3, "fp32-input MFMA peak 157.3 TFLOP/s (v_mfma_f32_16x16x4_f32); the bf16 MFMA peak is 16x that")
 
 
 def parse():
@@ -53,7 +60,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: --workload dist_selftest (CPU), or a one-GPU rehearsal of the multi-rank path with BENCH_ONE_GPU=1")
     ap.add_argument("--points", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="bounded CPU sample (frames)")
+    ap.add_argument("--cpu-frames", type=int, default=1, help="bounded CPU sample (frames)")
+    ap.add_argument("--vt-fp32", action="store_true", help="view-transform conv stacks in fp32 (the reference's fp32 island, "
+                    "BF/bevfusion.py:177) instead of bf16")
     return ap.parse_args()
 
 
@@ -181,7 +190,8 @@ class _ModelWorkload:
                     sub.to(memory_format=torch.channels_last)
         if self.channels_last and getattr(self.model, "pts_middle_encoder", None) is not None:
             self.model.pts_middle_encoder.bev_channels_last = True  # BEV map handed to the NHWC convs without a relayout
-        if self.amp and getattr(self.model, "view_transform", None) is not None:
+        self.vt_bf16 = self.amp and os.environ.get("BENCH_VT_FP32", "0") != "1"
+        if self.vt_bf16 and getattr(self.model, "view_transform", None) is not None:
             self.model.view_transform.conv_dtype = torch.bfloat16  # dense convs bf16, index paths + pooling fp32
         self.model.lidar_side_stream = os.environ.get("BENCH_SIDE_STREAM", "1") == "1"
         torch.backends.cudnn.benchmark = MIOPEN_FIND               # MIOpen exhaustive find (minutes of warm-up on a fresh box)
@@ -262,9 +272,18 @@ class _ModelWorkload:
             byts = sum((ni * ci + no * co) * 4 + P * 8 + 27 * ci * co * 4 for P, ci, co, ni, no in layers)
             # forward / dgrad run on the bf16 MFMA under bf16 autocast (layers with K % 8 == 0), wgrad always on the fp32 MFMA
             gemm_peak = 2500.0 if self.amp else 157.3
-            work["spconv_fwd"] = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=gemm_peak)
-            work["spconv_bwd"] = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=gemm_peak)
-            work["spconv_wgrad"] = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=157.3)
+            note = "bf16 MFMA dense peak ~2500 TFLOP/s" if self.amp else "fp32-input MFMA peak 157.3 TFLOP/s"
+            work["spconv_fwd"] = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=gemm_peak, peak_note=note,
+                                      scope="21 gather-GEMM launches (all sparse conv layers of the step)")
+            work["spconv_bwd"] = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=gemm_peak, peak_note=note,
+                                      scope="dgrad: 20 gather-GEMM launches")
+            wg = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=WGRAD_PEAK[0], peak_note=WGRAD_PEAK[1])
+            work["spconv_wgrad"] = dict(wg, scope="whole op x 21 layers: offset counts + main kernel + partial-slab reduce")
+            work["spconv_wgrad_main"] = dict(wg, scope="dominant kernel only (rocprofv3: spconv_wgrad*_kernel)")
+            # rulebooks actually built per step (SubM ones are shared per stage): N_in*16 + hash table 2*N*8 + P*8
+            uniq = {(P, ni, no) for P, _, _, ni, no in layers}
+            work["rulebook"] = dict(bound="hbm", bytes=sum(ni * 16 + 2 * max(ni, no) * 8 + P * 8 for P, ni, no in uniq),
+                                    scope="%d rulebook builds per step (hash / bitmap, pairs, row masks, row sort)" % len(uniq))
             self._layer_stats = layers
         if self.camera:
             vt = self.model.view_transform
@@ -275,32 +294,69 @@ class _ModelWorkload:
             C, D = vt.C, vt.D
             P = self.B * 6 * 32 * 88
             cells = self.B * 360 * 360
-            work["lift_splat_fwd"] = dict(bound="hbm", bytes=P * D * 4 + P * C * 4 + self.nk * 4 + cells * C * 4)
-            work["lift_splat_bwd"] = dict(bound="hbm", bytes=P * D * 4 + P * C * 4 + P * D * 4 + self.m * C * 4 + P * D * 4 + P * C * 4)
+            work["lift_splat_fwd"] = dict(bound="hbm", bytes=P * D * 4 + P * C * 4 + self.nk * 4 + cells * C * 4,
+                                          scope="fused outer product + gathers + bev_pool forward, one launch")
+            work["lift_splat_bwd"] = dict(bound="hbm", bytes=P * D * 4 + P * C * 4 + P * D * 4 + self.m * C * 4 + P * D * 4 + P * C * 4,
+                                          scope="fused backward, one launch")
         return work
 
     def cpu_baseline(self, frames):
-        """CPU oracle on the hand-written-op part of the same frames (the reference has no CPU path for
-        bev_pool / spconv; dense torch layers are not part of the oracle)."""
-        import oracle
+        """SURVEY 8(d) CPU baseline on `frames` frame(s) of this workload, all host cores: (i) hard voxelization = the C
+        oracle (single thread, as voxelization_cpu.cpp); (ii) bev_pool = restated QuickCumsum in fp32 (the reference's only
+        CPU-capable formulation), forward + backward; (iii) the whole 21-layer sparse encoder as gather -> mm -> index_add_,
+        forward + backward; (iv) the config-0 forward of the frame(s) (dense layers = torch.nn on the CPU, ops = oracle)
+        = BASELINE.json configs[0].  Returns (frames/s of (iv), description, parts in ms)."""
+        import copy
+        from oracle import cpu_pipeline as cp
         N = self.N
+        nf = max(1, min(frames, self.B))
+        threads = torch.get_num_threads()
+        model = copy.deepcopy(self.model).float().cpu().train()
+        pts = self.points_np[:nf]
+        parts = {}
+        mats = imgs = None
+        if self.camera:
+            mats = {k: self.inputs[k][:nf].float().cpu().numpy() for k in ("lidar2img", "cam2img", "cam2lidar", "img_aug_matrix",
+                                                                             "lidar_aug_matrix")}
+            imgs = self.inputs["imgs"][:nf].float().cpu()
+        tm = {}
         t0 = time.perf_counter()
-        n_done = 0
-        for f in range(frames):
-            pts = self.points_np[f % self.B]
-            vox, coors, num = oracle.hard_voxelize(pts, N["voxel_size"], N["point_cloud_range"], 10, 120000)
-            feats = oracle.voxel_mean(vox, num)
-            if self.lidar:
-                idx = np.concatenate([np.zeros((len(coors), 1), np.int32), coors], 1)
-                pair = oracle.rulebook_subm(idx, [1440, 1440, 41], 3)
-                w = np.zeros((16, 3, 3, 3, 5), np.float32)
-                f1 = oracle.spconv_fwd(feats, w, pair)
-                oi, pf, pb, osz = oracle.rulebook_sparse(idx, [1440, 1440, 41], 3, 2, 1)
-                oracle.spconv_fwd(f1, np.zeros((32, 3, 3, 3, 16), np.float32), pf)
-            n_done += 1
-        dt = time.perf_counter() - t0
-        what = "hard_voxelize + voxel mean" + (" + conv_input SubM 5->16 + first strided conv 16->32 (oracle, fp64 accumulate)" if self.lidar else "")
-        return n_done / dt, "%d frame(s): %s; the dense layers and the remaining sparse layers are not timed on the CPU" % (frames, what)
+        with torch.no_grad():
+            cp.model_forward(model, pts, imgs, mats, N, timings=tm)
+        full = time.perf_counter() - t0
+        parts["config0_forward_ms"] = round(full * 1e3 / nf, 1)
+        parts.update({"config0_" + k + "_ms": round(v * 1e3 / nf, 1) for k, v in tm.items()})
+        if self.camera:
+            vt = model.view_transform
+            gf, kept, ranks, order = cp.bev_geometry(vt, mats, nf)
+            x = torch.randn(gf.shape[0], vt.C, requires_grad=True)
+            t0 = time.perf_counter()
+            out = cp.bev_pool_quickcumsum(x, torch.from_numpy(gf), torch.from_numpy(ranks), nf, vt._nx_host[2], vt._nx_host[0],
+                                          vt._nx_host[1])
+            t1 = time.perf_counter()
+            out.backward(torch.ones_like(out))
+            parts["bev_pool_quickcumsum_fwd_ms"] = round((t1 - t0) * 1e3 / nf, 1)
+            parts["bev_pool_quickcumsum_bwd_ms"] = round((time.perf_counter() - t1) * 1e3 / nf, 1)
+            parts["bev_pool_rows_per_frame"] = int(gf.shape[0] // nf)
+        if self.lidar:
+            t0 = time.perf_counter()
+            vf, coords = cp.voxelize_mean(pts, N)
+            parts["voxelize_oracle_1thread_ms"] = round((time.perf_counter() - t0) * 1e3 / nf, 1)
+            t0 = time.perf_counter()
+            bev = cp.sparse_encoder_forward(model.pts_middle_encoder, vf, coords, nf)
+            t1 = time.perf_counter()
+            bev.square().mean().backward()
+            parts["sparse_encoder_fwd_ms"] = round((t1 - t0) * 1e3 / nf, 1)
+            parts["sparse_encoder_bwd_ms"] = round((time.perf_counter() - t1) * 1e3 / nf, 1)
+        cpu = "?"
+        try:
+            cpu = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        except (OSError, IndexError):
+            pass
+        what = ("%d frame(s), FORWARD ONLY (BASELINE configs[0]): oracle voxelize/rasterise/geometry + torch.nn dense layers + "
+                "QuickCumsum bev_pool (fp32) + gather-mm-index_add sparse encoder; os.cpu_count()=%s, torch threads=%d, CPU=%s"
+                % (nf, os.cpu_count(), threads, cpu))
+        return nf / full, what, parts, threads
 
 
 class LidarOnly(_ModelWorkload):
@@ -439,6 +495,8 @@ def main():
             dist.init_process_group("nccl")
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
 
+    if args.vt_fp32:
+        os.environ["BENCH_VT_FP32"] = "1"
     from bevfusion_amd import _lib
     cls = WORKLOADS[args.workload]
     if cpu_mode:
@@ -491,33 +549,41 @@ def main():
         ops = {op: {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": cnt / args.steps}
                for op, (ms, cnt) in prof.items() if cnt}
         # dominant hand-written op of the step = the one with the largest accumulated event time
-        dom = max((op for op in work if prof.get(op, (0, 0))[1]), key=lambda o: prof[o][0], default=None)
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value is the
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement committed under profiles/ (same batch-4 sizes)
-        pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        except (OSError, KeyError, ValueError):
-            pass
-        roof = None
-        if dom is not None:
-            ms, cnt = prof[dom]
-            w = work[dom]
+        dom = max((op for op in work if prof.get(op, (0, 0))[1] and op != "spconv_wgrad_main"), key=lambda o: prof[o][0], default=None)
+        # HBM traffic: PMC counters cannot be read from inside this process; the value is the rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE measurement committed under profiles/ (same batch-4 sizes), tagged with its source
+        pmc, pmc_src = {}, None
+        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
+                pmc_src = "profiles/" + cand + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate run; not measured by this run)"
+                break
+            except (OSError, KeyError, ValueError):
+                continue
+
+        def roof_of(op):
+            ms, cnt = prof[op]
+            w = work[op]
             sec_per_step = ms * 1e-3 / args.steps
+            traffic = int(pmc[op]["hbm_bytes"]) if (op in pmc and args.batch == 4 and args.points == 40000) else None
+            r = {"kernel": op, "bound": w["bound"], "ms_per_step": round(ms / args.steps, 5), "launches_per_step": cnt / args.steps,
+                 "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None}
+            if "scope" in w:
+                r["scope"] = w["scope"]
             if w["bound"] == "hbm":
                 ach = w["bytes"] / sec_per_step / 1e9
-                traffic = int(pmc[dom]["hbm_bytes"]) if (dom in pmc and args.batch == 4) else None
-                roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_step": int(w["bytes"]),
-                        "ms_per_step": round(ms / args.steps, 5), "launches_per_step": cnt / args.steps}
+                r.update(achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                         algorithmic_bytes_per_step=int(w["bytes"]))
             else:
                 ach = w["flops"] / sec_per_step / 1e12
-                roof = {"bound": "mfma", "kernel": dom + " (all sparse conv layers of the step)", "achieved": round(ach, 2),
-                        "peak": w["unit_peak"], "unit": "TFLOP/s", "frac": round(ach / w["unit_peak"], 4),
-                        "traffic": int(pmc[dom]["hbm_bytes"]) if (dom in pmc and args.batch == 4 and args.workload == "full") else None,
-                        "algorithmic_flops_per_step": w["flops"], "algorithmic_bytes_per_step": int(w["bytes"]),
-                        "ms_per_step": round(ms / args.steps, 5), "launches_per_step": cnt / args.steps,
-                        "note": "peaks from MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s, bf16 MFMA ~2500 TFLOP/s dense"}
+                r.update(achieved=round(ach, 2), peak=w["unit_peak"], unit="TFLOP/s", frac=round(ach / w["unit_peak"], 4),
+                         algorithmic_flops_per_step=w["flops"], algorithmic_bytes_per_step=int(w["bytes"]),
+                         peak_note=w.get("peak_note", ""))
+                r["hbm_frac_on_algorithmic_bytes"] = round(w["bytes"] / sec_per_step / 1e9 / HBM_PEAK_GBS, 4)
+            return r
+
+        roofline_ops = [roof_of(op) for op in work if prof.get(op, (0, 0))[1]]
+        roof = roof_of(dom) if dom is not None else None
         line = {
             "metric": "nuScenes frames/sec (6-cam+LiDAR BEVFusion fwd+bwd)" if args.workload == "full" else
                       "nuScenes frames/sec (%s)" % args.workload,
@@ -528,8 +594,10 @@ def main():
                        "points_per_frame": args.points, "frustum_rows_kept": wl.nk, "bev_intervals": wl.m,
                        "parallelism": ("dp%d (%s, RCCL gradient all-reduce)" % (world, "DDP buckets" if GRAD_SYNC == "ddp" else "one flat all-reduce per dtype after the backward")) if world > 1 and hasattr(wl, "step_model")
                        else "independent frames per rank"},
-            "roofline": roof, "ops": ops,
+            "roofline": roof, "roofline_ops": roofline_ops, "ops": ops,
         }
+        if hasattr(wl, "vt_bf16"):
+            line["config"]["view_transform_conv_dtype"] = "bf16" if wl.vt_bf16 else "fp32 (reference fp32 island)"
         if hasattr(wl, "n_params"):
             line["config"]["trainable_params"] = wl.n_params
         if torch.is_tensor(first_loss) and torch.is_tensor(last_loss):
@@ -540,8 +608,12 @@ def main():
             line["data"] = "synthetic (CPU plumbing rehearsal, not a performance number)"
             line["config"]["grad_fingerprint"] = wl.grad_fingerprint()
         if world == 1 and not args.no_cpu_baseline and not cpu_mode:
-            v, sample = wl.cpu_baseline(args.cpu_frames)
-            line["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample}
+            res = wl.cpu_baseline(args.cpu_frames)
+            line["cpu_baseline"] = {"value": round(res[0], 4), "unit": "frames/s", "cores": res[3] if len(res) > 3 else 1,
+                                    "kind": "port", "sample": res[1]}
+            if len(res) > 2:
+                line["cpu_baseline"]["unit"] = "frames/s (forward only)"
+                line["cpu_baseline"]["parts_ms_per_frame"] = res[2]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if cpu_mode and os.environ.get("BENCH_FINGERPRINT_DIR"):  # every rank: DDP must leave identical gradients

@@ -1787,7 +1787,8 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
   int S = wgrad_splits(KV, GI, GJ, n_rows);
   if (workspace_bytes < bfhip_spconv_wgrad_workspace_bytes(KV, Cin, Cout, n_rows) || !workspace) { set_error("spconv_wgrad: workspace too small"); return BFHIP_E_WORKSPACE; }
   float *partial = (float *)workspace;
-  ProfScope ps;
+  ProfScope ps, ps_op;
+  prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps_op);  // the whole op: counts + main + reduce
   if (vec && KV <= 64) {
     // the row-streamed MFMA kernel: R = 4 | 2 for the narrow square stages (C = 16 | 32), 64 x 64 tiles otherwise
     const int R = (Cin == Cout && Cin == 16) ? 4 : (Cin == Cout && Cin == 32) ? 2 : 1;
@@ -1807,7 +1808,7 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
     // per-offset pair counts (weights of the decomposition) behind the slabs
     int *counts = (int *)(partial + ((size_t)P + (size_t)g.NR * KV * GI * GJ) * 4096);
     hipLaunchKernelGGL(wgrad_offset_counts_kernel, dim3(KV * kCountSlices), dim3(256), 0, stream, pairs, ld, n_rows, counts);
-    prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
+    prof_begin(BFHIP_OP_SPCONV_WGRAD_MAIN, stream, &ps);
 #define BFHIP_WG_LAUNCH(RR, IO)                                                                                          \
   hipLaunchKernelGGL((spconv_wgrad64p_kernel<RR, IO>), dim3(P), dim3(256), 0, stream, in, Cin, dout, Cout, pairs, ld, KV, \
                      n_rows, g, GI, GJ, perm, counts, partial)
@@ -1817,17 +1818,19 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
 #undef BFHIP_WG_LAUNCH
     prof_end(&ps);  // the events bracket the dominant kernel only, so their average matches rocprof's for that kernel
     hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3(ceil_div((long long)KV * Cin * Cout, 64)), dim3(256), 0, stream, partial, KV, Cin, Cout, GI, GJ, g, P, counts, dW);
+    prof_end(&ps_op);
     return check_launch("spconv_wgrad");
   }
   // channel counts that are not multiples of 4 (the 5-channel input layer) or more than 64 offsets: scalar-load kernel
   GI = (Cin + 31) / 32;
   const long long waves = (long long)KV * S * GI * GJ;
-  prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps);
+  prof_begin(BFHIP_OP_SPCONV_WGRAD_MAIN, stream, &ps);
   hipLaunchKernelGGL((spconv_wgrad_kernel<2, 4>), dim3(ceil_div(waves * 64, 256)), dim3(256), 0, stream, (const float *)in, Cin, (const float *)dout, Cout,
                      pairs, ld, KV, n_rows, S, GI, GJ, partial);
   prof_end(&ps);
   long long total = (long long)KV * Cin * Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, partial, S, KV, Cin, Cout, dW);
+  prof_end(&ps_op);
   return check_launch("spconv_wgrad");
 }
 

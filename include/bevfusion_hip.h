@@ -51,8 +51,9 @@ extern "C" {
 #define BFHIP_OP_BEV_AUX 9
 #define BFHIP_OP_SCATTER_FWD 10
 #define BFHIP_OP_SCATTER_BWD 11
-#define BFHIP_OP_SPCONV_WGRAD 12
+#define BFHIP_OP_SPCONV_WGRAD 12 /* whole op: offset counts + main kernel + partial-slab reduce */
 #define BFHIP_OP_RASTER 13
+#define BFHIP_OP_SPCONV_WGRAD_MAIN 14 /* the dominant kernel alone (what rocprofv3 lists as spconv_wgrad64p_kernel) */
 #define BFHIP_OP_COUNT 16
 
 int bfhip_abi_version(void);
