@@ -311,7 +311,11 @@ class _ModelWorkload:
         N = self.N
         nf = max(1, min(frames, self.B))
         threads = torch.get_num_threads()
-        model = copy.deepcopy(self.model).float().cpu().train()
+        side, self.model._side_stream = self.model._side_stream, None  # HIP stream handles do not deep-copy
+        try:
+            model = copy.deepcopy(self.model).float().cpu().train()
+        finally:
+            self.model._side_stream = side
         pts = self.points_np[:nf]
         parts = {}
         mats = imgs = None

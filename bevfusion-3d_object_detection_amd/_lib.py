@@ -92,6 +92,15 @@ SIGNATURES = {
     "bfhip_draw_heatmap": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, ctypes.c_double, _c_int, _c_vp, _c_vp]),
     "bfhip_gaussian_focal_loss_workspace_bytes": (_c_sz, [ctypes.c_longlong]),
     "bfhip_gaussian_focal_loss": (_c_int, [_c_vp, _c_vp, ctypes.c_longlong, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_conv2d_supported": (_c_int, [_c_int] * 10),
+    "bfhip_conv2d_stat_rows": (_c_int, [_c_int] * 3),
+    "bfhip_conv2d_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp, _c_vp]),
+    "bfhip_conv2d_dgrad_workspace_bytes": (_c_sz, [_c_int] * 4),
+    "bfhip_conv2d_dgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_conv2d_wgrad_workspace_bytes": (_c_sz, [_c_int] * 7),
+    "bfhip_conv2d_wgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_bn2d_fwd_partials": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +
+                                [_c_vp] * 4 + [_c_vp, _c_int, _c_vp]),
     "bfhip_query_losses": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 4),
 }
 

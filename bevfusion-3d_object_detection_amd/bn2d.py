@@ -19,11 +19,11 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 _WS = {}
 
 
-def _apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu):
+def _apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial=None):
     ext = _lib.torch_ext()
-    if ext is not None:  # C++ autograd front-end: same kernels, ~3x less host time per call
+    if ext is not None and partial is None:  # C++ autograd front-end: same kernels, ~3x less host time per call
         return ext.bn2d(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu)
-    return _BN2dFunction.apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu)
+    return _BN2dFunction.apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial)
 
 
 _SIZES = {}
@@ -51,7 +51,7 @@ class _BN2dFunction(torch.autograd.Function):
     """y = act(BN_train(x) [+ residual]); x, residual, y channels-last [N, C, H, W], f32 or bf16."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial=None):
         N, C, H, W = x.shape
         M, dt = N * H * W, _DT[x.dtype]
         res = None
@@ -61,10 +61,16 @@ class _BN2dFunction(torch.autograd.Function):
         y = torch.empty_like(x)  # keeps the channels-last strides
         stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         stream = _lib.stream_of(x)
-        ws = _workspace(x.device, _ws_bytes(M, C, dt), stream)
-        _lib.call("bfhip_bn2d_fwd", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps, momentum,
-                  1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(), y.data_ptr(),
-                  ws.data_ptr(), ws.numel(), stream)
+        if partial is not None:
+            # the producing convolution accumulated the column sums in its epilogue (conv2d.py): no statistics pass
+            _lib.call("bfhip_bn2d_fwd_partials", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps,
+                      momentum, 1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(),
+                      y.data_ptr(), partial.data_ptr(), partial.shape[0], stream)
+        else:
+            ws = _workspace(x.device, _ws_bytes(M, C, dt), stream)
+            _lib.call("bfhip_bn2d_fwd", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps, momentum,
+                      1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(), y.data_ptr(),
+                      ws.data_ptr(), ws.numel(), stream)
         keep_y = relu and residual is not None  # otherwise the ReLU mask is recomputed from x in the backward
         ctx.save_for_backward(x, y if keep_y else None, stats, weight)
         ctx.relu, ctx.has_res = relu, residual is not None
@@ -88,7 +94,7 @@ class _BN2dFunction(torch.autograd.Function):
                   1 if ctx.relu else 0, dx.data_ptr(), _lib.ptr(dres), dgb.data_ptr(), ws.data_ptr(), ws.numel(), stream)
         if dres is not None and ctx.res_dtype != dres.dtype:
             dres = dres.to(ctx.res_dtype)
-        return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None
+        return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None, None
 
 
 class _LazyBatchCounter:
@@ -126,8 +132,11 @@ class BatchNorm2dAct(_LazyBatchCounter, nn.BatchNorm2d):
         relu = self.act if relu is None else relu
         if self.fusable(x):
             self._pending_batches += 1
+            partial = getattr(x, "_bfhip_stat_partial", None)  # statistics from the producing conv's epilogue (conv2d.py)
+            if partial is not None and (partial.shape[2] != x.shape[1] or partial.shape[0] != -(-(x.numel() // x.shape[1]) // 128)):
+                partial = None
             return _apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
-                          relu)
+                          relu, partial)
         self._flush_batches()
         out = super().forward(x)
         if residual is not None:

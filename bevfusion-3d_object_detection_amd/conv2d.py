@@ -1,0 +1,158 @@
+"""Dense 2-D convolution on channels-last bf16 activations through csrc/conv2d.hip (implicit GEMM on the matrix cores,
+forward + data gradient + weight gradient), behind `torch.nn.Conv2d`'s interface.
+
+`Conv2d` IS an `nn.Conv2d` (same parameters / state-dict keys as the reference's `build_conv_layer(dict(type='Conv2d'))`
+layers: ConvFuser BF/bevfusion_head.py:26-38, SECOND mmdet3d/models/backbones/second.py:27-95, SECONDFPN
+necks/second_fpn.py:30-94, shared_conv BF/bevfusion_head.py:95-102, depthnet / downsample BF/depth_lss.py:592-620,
+GeneralizedLSSFPN BF/bevfusion_necks.py:50-72).  Its forward takes the HIP kernels when the call is one they serve -- a
+CUDA tensor under bf16 autocast (or already bf16), groups = 1, zero padding, channel counts that are multiples of 8 -- and
+torch's own convolution otherwise (fp32 islands, CPU tensors, odd channel counts).  `BFHIP_CONV2D=0` switches the HIP path
+off (A/B runs).
+
+In training, a bias-free convolution also emits the per-row-block column sums / sums of squares of its fp32 accumulators;
+they ride on the output tensor (`y._bfhip_stat_partial`) and the fused BatchNorm that follows (bn2d.BatchNorm2dAct) starts
+from them instead of re-reading the activation for its statistics pass.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+ENABLED = os.environ.get("BFHIP_CONV2D", "1") == "1"
+MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))  # tiny maps: the library's small-problem kernels win
+_WS = {}
+
+
+def _workspace(device, nbytes, stream):
+    key = (device, stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS[key] = torch.empty(max(int(nbytes), 1 << 24), dtype=torch.uint8, device=device)
+    return buf
+
+
+def _nhwc_view(t):
+    """(pointer tensor, pixel pitch) when t [N, C, H, W] is channels-last dense or a channel slice of such a tensor."""
+    N, C, H, W = t.shape
+    sn, sc, sh, sw = t.stride()
+    if sc == 1 and sw >= C and sh == W * sw and (sn == H * W * sw or N == 1) and sw % 8 == 0 and t.data_ptr() % 16 == 0:
+        return sw
+    return None
+
+
+def _as_nhwc_bf16(t):
+    if t.dtype != torch.bfloat16:
+        t = t.to(torch.bfloat16)
+    if _nhwc_view(t) is None:
+        t = t.contiguous(memory_format=torch.channels_last)
+        if _nhwc_view(t) is None:  # C == 1 or W == 1 corner cases of torch's stride normalisation
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return t
+
+
+def _weight_ohwi(w):
+    """bf16 [Cout][KH][KW][Cin] memory of a conv weight [Cout, Cin, KH, KW]."""
+    if w.dtype != torch.bfloat16:
+        w = w.to(torch.bfloat16)
+    p = w.permute(0, 2, 3, 1)
+    return p if p.is_contiguous() else p.contiguous()
+
+
+class _Conv2dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, emit_stats):
+        x = _as_nhwc_bf16(x)
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+        OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+        w = _weight_ohwi(weight)
+        y = torch.empty((N, OH, OW, Cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+        partial = None
+        if emit_stats:
+            rows = _lib.load().bfhip_conv2d_stat_rows(N, OH, OW)
+            partial = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
+        b32 = None
+        if bias is not None:
+            b32 = bias if bias.dtype == torch.float32 else bias.float()
+        _lib.call("bfhip_conv2d_fwd", x.data_ptr(), _nhwc_view(x), w.data_ptr(), _lib.ptr(b32), y.data_ptr(), Cout, N, H, W, Cin,
+                  Cout, KH, KW, stride, pad, dil, 0, _lib.ptr(partial), _lib.stream_of(x))
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad, dil)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        if partial is not None:
+            ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, dy, _dpartial):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil = ctx.geom
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        dy = _as_nhwc_bf16(dy)
+        OH, OW = dy.shape[2], dy.shape[3]
+        stream = _lib.stream_of(x)
+        lib = _lib.load()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+            ws = _workspace(x.device, lib.bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), stream)
+            _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
+                      W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
+        if ctx.needs_input_grad[1]:
+            out_bf16 = weight.dtype == torch.bfloat16
+            dw = torch.empty((Cout, KH, KW, Cin), dtype=weight.dtype if out_bf16 else torch.float32,
+                             device=x.device).permute(0, 3, 1, 2)
+            ws = _workspace(x.device, lib.bfhip_conv2d_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, KH, KW), stream)
+            _lib.call("bfhip_conv2d_wgrad", x.data_ptr(), _nhwc_view(x), dy.data_ptr(), _nhwc_view(dy), dw.data_ptr(), N, H, W, Cin,
+                      Cout, KH, KW, stride, pad, dil, 1 if out_bf16 else 0, ws.data_ptr(), ws.numel(), stream)
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
+        return dx, dw, db, None, None, None, None
+
+
+def _one(v):
+    if isinstance(v, (tuple, list)):
+        return v[0] if all(a == v[0] for a in v) else None
+    return v
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, emit_stats=False):
+    """y = conv2d(x, weight, bias) on the HIP path (bf16, channels-last); returns (y, stat_partial | None)."""
+    return _Conv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats))
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose forward runs csrc/conv2d.hip when it can (module docstring)."""
+
+    def hip_eligible(self, x):
+        if not (ENABLED and x.is_cuda and x.dim() == 4 and self.groups == 1 and self.padding_mode == "zeros"
+                and not isinstance(self.padding, str)):
+            return False
+        low = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                                            and x.dtype in (torch.float32, torch.bfloat16))
+        if not low or self.weight.dtype not in (torch.bfloat16, torch.float32):
+            return False
+        s, p, d = _one(self.stride), _one(self.padding), _one(self.dilation)
+        if s is None or p is None or d is None:
+            return False
+        N, Cin, H, W = x.shape
+        if N * H * W < MIN_PIXELS:
+            return False
+        return bool(_lib.load().bfhip_conv2d_supported(N, H, W, Cin, self.out_channels, self.kernel_size[0], self.kernel_size[1],
+                                                       s, p, d))
+
+    def forward(self, x):
+        if not self.hip_eligible(x):
+            return super().forward(x)
+        emit = self.training and self.bias is None and torch.is_grad_enabled()
+        y, partial = conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation), emit)
+        if partial is not None:
+            y._bfhip_stat_partial = partial  # picked up by the fused BatchNorm that follows (bn2d.BatchNorm2dAct)
+        return y

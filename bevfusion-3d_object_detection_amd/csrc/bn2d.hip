@@ -455,6 +455,24 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
   return check_launch("bn2d_fwd");
 }
 
+BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta,
+                                         long long M, int C, int dtype, float eps, float momentum, int relu,
+                                         float *running_mean, float *running_var, float *stats, void *y,
+                                         const float *partial, int nblk, void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  BFHIP_REQUIRE(bfhip_bn2d_supported(M, C, dtype), "bn2d_fwd_partials: unsupported shape M=%lld C=%d dtype=%d", M, C, dtype);
+  BFHIP_REQUIRE(x && gamma && beta && stats && y && partial && nblk > 0, "bn2d_fwd_partials: null pointer");
+  BFHIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0,
+                "bn2d_fwd_partials: tensors must be 16-byte aligned");
+  dim3 grid;
+  Map mp = make_map(M, C, dtype, &grid);
+  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, C, eps, momentum,
+                     gamma, beta, stats, running_mean, running_var);
+  if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
+  else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
+  return check_launch("bn2d_fwd_partials");
+}
+
 BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma,
                                 long long M, int C, int dtype, int relu, void *dx, void *dres, float *dgb,
                                 void *workspace, size_t workspace_bytes, void *stream_) {

@@ -1,0 +1,592 @@
+// conv2d.hip -- dense 2-D convolution on channels-last (NHWC) bf16 activations as an implicit GEMM on the gfx950 matrix
+// cores: forward, data gradient and weight gradient, with BatchNorm statistics accumulated in the forward epilogue.
+//
+// Layers served (SURVEY 8 a-8 ... a-11): ConvFuser 336->256 3x3 (BF/bevfusion_head.py:26-38), SECOND's twelve 3x3 convs and
+// SECONDFPN's 1x1 conv (mmdet3d/models/backbones/second.py:27-95, necks/second_fpn.py:30-94), the head's shared_conv
+// (BF/bevfusion_head.py:95-102), depthnet / downsample of the view transform (BF/depth_lss.py:592-620) and the LSS-FPN
+// lateral / fpn convs (BF/bevfusion_necks.py:50-72).  Any kernel size / stride / padding / dilation, groups = 1,
+// channel counts that are multiples of 8.
+//
+// Formulation.  y[m][co] = sum_k A[m][k] * Wt[co][k], m = (n, oh, ow), k = (kh, kw, ci): the weight of a channels-last conv,
+// [Cout][KH][KW][Cin], IS the row-major B^T operand; A is never materialised -- each 16-byte piece (8 channels of one tap
+// of one pixel) is fetched straight from the activation into LDS by `global_load_lds_dwordx4` with a per-lane source
+// address (padding / tails read a zero page).  The data gradient is the same kernel in "transposed" mode (rows = input
+// pixels, gathered tensor = dy, oh = (ih + pad - kh*dil) / stride when divisible) over the [Cin][KH][KW][Cout] transpose
+// of the weight.  The weight gradient dW[co][k] = sum_m dy[m][co] * A[m][k] reduces over pixels: both operands are staged
+// pixel-major and read with the transposing LDS read `ds_read_b64_tr_b16`, the pixel range is split over workgroups and
+// the fp32 partial slabs are summed in a fixed order.
+//
+// Tile: 128 rows x (64 | 128) columns per 256-thread workgroup, K step 64 (bf16), 4 waves as 2 x 2, each wave a
+// 64 x (32 | 64) block of `v_mfma_f32_32x32x16_bf16` accumulators; two LDS buffers per operand, the next step's loads are
+// issued before the current step's MFMAs (one barrier per step).  LDS images are written linearly by the DMA; the bank
+// swizzle lives in the SOURCE chunk a lane fetches and in the read address (same involution on both sides).
+#include "common.h"
+
+namespace bfhip {
+namespace {
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __attribute__((aligned(64))) unsigned g_zero_page[16];  // source of every padded / out-of-range piece
+
+struct ConvGeom {
+  // gathered tensor [N, H, W, C] (pixel pitch ldx elements); GEMM rows = pixels of an [N, OH, OW] grid
+  int N, H, W, C, ldx;
+  int OH, OW;
+  int KH, KW, stride, pad, dil;
+  int transposed;  // 0: src = row * stride - pad + k * dil     1: t = row + pad - k * dil, src = t / stride if divisible
+  int nq;          // KH * KW * C / 8: number of 16-byte pieces along K
+  long long M;     // N * OH * OW
+  int Kout;        // GEMM columns (output channels of this GEMM)
+  int ldw;         // weight row pitch in elements (= KH * KW * C)
+  int ldy;         // output pixel pitch in elements
+};
+
+__device__ __forceinline__ unsigned rne_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void glds16(const void *src, void *lds_dst) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
+                                   (void __attribute__((address_space(3))) *)lds_dst, 16, 0, 0);
+}
+
+// tap table: piece q -> (kh * dil) << 24 | (kw * dil) << 16 | ci
+__device__ __forceinline__ void build_tap_table(unsigned *taps, const ConvGeom &g) {
+  for (int q = threadIdx.x; q < g.nq; q += blockDim.x) {
+    int k = q * 8;
+    int tap = k / g.C, ci = k - tap * g.C;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    taps[q] = ((unsigned)(kh * g.dil) << 24) | ((unsigned)(kw * g.dil) << 16) | (unsigned)ci;
+  }
+}
+
+// source address of piece (dh, dw, ci) for the row whose bases are (nb, hb, wb); nullptr -> zero page
+__device__ __forceinline__ const bf16_t *piece_src(const bf16_t *x, const ConvGeom &g, bool row_ok, int nb, int hb, int wb,
+                                                   unsigned info) {
+  const int dh = info >> 24, dw = (info >> 16) & 0xff, ci = info & 0xffff;
+  int ih, iw;
+  bool ok = row_ok;
+  if (!g.transposed) {
+    ih = hb + dh;
+    iw = wb + dw;
+  } else {
+    int th = hb - dh, tw = wb - dw;
+    ok = ok && th >= 0 && tw >= 0;
+    if (g.stride == 1) { ih = th; iw = tw; }
+    else {
+      ih = th / g.stride;
+      iw = tw / g.stride;
+      ok = ok && ih * g.stride == th && iw * g.stride == tw;
+    }
+  }
+  ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+  return ok ? x + ((size_t)(nb + ih * g.W + iw) * g.ldx + ci) : (const bf16_t *)g_zero_page;
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+// LDS: A[2][128][64] bf16, B[2][BN][64] bf16, tap table.  Rows are 128 bytes (8 pieces); piece c of row r sits at
+// position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 lane group touches land on 16 distinct 16-byte slots.
+template <int WN, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt,
+                                                            const float *__restrict__ bias, void *__restrict__ y,
+                                                            float *__restrict__ stat_partial, ConvGeom g, int tiles_m,
+                                                            int tiles_n) {
+  constexpr int BN = WN * 64, BM = 128, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char *sA = smem, *sB = smem + 2 * A_BYTES;
+  unsigned *taps = (unsigned *)(smem + 2 * A_BYTES + 2 * B_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles_m * tiles_n);
+  const int tn = (int)(lb % tiles_n), tm = (int)(lb / tiles_n);
+  const long long m0 = (long long)tm * BM;
+  const int n0 = tn * BN;
+
+  build_tap_table(taps, g);
+
+  // ---- per-lane staging state: 4 A rows (one per DMA instruction) and WN*2 B rows
+  const int lrow = lane >> 3, lpos = lane & 7;
+  int nb[4], hb[4], wb[4];
+  bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long m = m0 + w * 32 + i * 8 + lrow;
+    rok[i] = m < g.M;
+    long long mm = rok[i] ? m : 0;
+    int n = (int)(mm / ((long long)g.OH * g.OW));
+    int rem = (int)(mm - (long long)n * g.OH * g.OW);
+    int oh = rem / g.OW, ow = rem - oh * g.OW;
+    nb[i] = n * g.H * g.W;
+    hb[i] = g.transposed ? oh + g.pad : oh * g.stride - g.pad;
+    wb[i] = g.transposed ? ow + g.pad : ow * g.stride - g.pad;
+  }
+  const bf16_t *wrow[WN * 2];
+#pragma unroll
+  for (int i = 0; i < WN * 2; ++i) {
+    int co = n0 + w * (WN * 16) + i * 8 + lrow;
+    wrow[i] = co < g.Kout ? wt + (size_t)co * g.ldw : nullptr;
+  }
+  __syncthreads();  // tap table ready
+
+  const int nt = (g.nq + 7) >> 3;
+  auto stage = [&](int t, int buf) {
+    unsigned char *dA = sA + buf * A_BYTES + (w * 32) * 128;
+    unsigned char *dB = sB + buf * B_BYTES + (w * (WN * 16)) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int swz = (i * 4 + (lane >> 4)) & 7;  // ((row >> 1) & 7) of row = w*32 + i*8 + lrow
+      const int q = t * 8 + (lpos ^ swz);
+      const bf16_t *src = q < g.nq ? piece_src(x, g, rok[i], nb[i], hb[i], wb[i], taps[q]) : (const bf16_t *)g_zero_page;
+      glds16(src, dA + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < WN * 2; ++i) {
+      const int swz = (i * 4 + (lane >> 4)) & 7;  // rows of B start at multiples of 16 per wave: same form
+      const int q = t * 8 + (lpos ^ swz);
+      const bf16_t *src = (wrow[i] && q < g.nq) ? wrow[i] + (size_t)q * 8 : (const bf16_t *)g_zero_page;
+      glds16(src, dB + i * 1024);
+    }
+  };
+
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int wm = w >> 1, wn = w & 1;
+  const int l31 = lane & 31, lh = lane >> 5, rswz = (lane >> 1) & 7;  // ((row >> 1) & 7) of row = 32*j + l31
+  const int aoff = (wm * 64 + l31) * 128, boff = (wn * (WN * 32) + l31) * 128;
+
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    const unsigned char *pA = sA + buf * A_BYTES + aoff, *pB = sB + buf * B_BYTES + boff;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int pos = ((2 * ks + lh) ^ rswz) << 4;
+      bf16x8 a[2], b[WN];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8 *)(pA + mi * 32 * 128 + pos);
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) b[ni] = *(const bf16x8 *)(pB + ni * 32 * 128 + pos);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with the staging buffers: reuse them for the epilogue
+
+  // ---- BatchNorm statistics of the raw accumulators (rows beyond M are exact zeros): per-column sum / sum of squares
+  if (stat_partial) {
+    float *sred = (float *)(smem);  // [2 (wm)][BN][2]
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { float v = acc[mi][ni][r]; s += v; s2 += v * v; }
+      s += __shfl_xor(s, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0) {
+        int col = wn * (WN * 32) + ni * 32 + l31;
+        sred[(wm * BN + col) * 2 + 0] = s;
+        sred[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.Kout) {
+      float s = sred[tid * 2] + sred[(BN + tid) * 2], s2 = sred[tid * 2 + 1] + sred[(BN + tid) * 2 + 1];
+      stat_partial[((size_t)tm * 2 + 0) * g.Kout + n0 + tid] = s;
+      stat_partial[((size_t)tm * 2 + 1) * g.Kout + n0 + tid] = s2;
+    }
+    __syncthreads();
+  }
+
+  // ---- output: accumulators -> LDS [128][BN] (row-major) -> 16-byte coalesced stores
+  constexpr int ESZ = OUT_F32 ? 4 : 2;
+  constexpr int ROWB = BN * ESZ;
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    const int col = wn * (WN * 32) + ni * 32 + l31;
+    const float bv = (bias && n0 + col < g.Kout) ? bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = acc[mi][ni][r] + bv;
+        if (OUT_F32) *(float *)(smem + row * ROWB + col * 4) = v;
+        else *(bf16_t *)(smem + row * ROWB + col * 2) = (bf16_t)rne_bf16(v);
+      }
+  }
+  __syncthreads();
+  constexpr int CPR = ROWB / 16;  // 16-byte pieces per row
+  constexpr int EPC = 16 / ESZ;   // elements per piece
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    const long long m = m0 + row;
+    const int col = n0 + c * EPC;
+    if (m >= g.M || col >= g.Kout) continue;
+    unsigned char *dst = (unsigned char *)y + ((size_t)m * g.ldy + col) * ESZ;
+    const unsigned char *src = smem + row * ROWB + c * 16;
+    if (col + EPC <= g.Kout && (((uintptr_t)dst) & 15) == 0) *(uint4 *)dst = *(const uint4 *)src;
+    else
+      for (int e = 0; e < EPC && col + e < g.Kout; ++e) {
+        if (OUT_F32) ((float *)dst)[e] = ((const float *)src)[e];
+        else ((bf16_t *)dst)[e] = ((const bf16_t *)src)[e];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][k] = sum over pixels of dy[m][co] * A[m][k].  LDS tiles are pixel-major: dy [64][128 co], A [64][128 k]
+// (256-byte rows; piece c of row r at position c ^ (((r & 3) << 2) | ((r >> 2) & 3)), conflict-free for the
+// transposing read).  ds_read_b64_tr_b16 hands each lane 4 consecutive pixels of ONE column: the K-major fragment the
+// 32x32x16 MFMA wants, for both operands.
+struct WgradGeom {
+  ConvGeom c;      // forward geometry of the conv (gathered tensor = x)
+  int Cout, ldg;   // dy channels and pixel pitch
+  int splits;      // pixel range split
+  long long rows_per_split;  // multiple of 64
+  int tiles_co, tiles_k;
+};
+
+__device__ __forceinline__ int tr_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+                                                            float *__restrict__ slab, WgradGeom wg) {
+  constexpr int BP = 64, T_BYTES = BP * 256;  // one tile: 64 pixels x 128 columns bf16
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char *sG = smem, *sX = smem + 2 * T_BYTES;
+  unsigned *taps = (unsigned *)(smem + 4 * T_BYTES);
+  const ConvGeom &g = wg.c;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles = wg.tiles_co * wg.tiles_k;
+  const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles * wg.splits);
+  const int split = (int)(lb / tiles), tile = (int)(lb - (long long)split * tiles);
+  const int tco = tile / wg.tiles_k, tk = tile - tco * wg.tiles_k;
+  const int co0 = tco * 128, q0 = tk * 16;  // first dy channel, first K piece of this tile
+  build_tap_table(taps, g);
+
+  const long long p_begin = (long long)split * wg.rows_per_split;
+  long long p_end = p_begin + wg.rows_per_split;
+  if (p_end > g.M) p_end = g.M;
+  const int nsteps = p_end > p_begin ? (int)((p_end - p_begin + BP - 1) / BP) : 0;
+
+  // staging: one DMA instruction = 4 rows x 256 B; wave w stages rows [16w, 16w + 16): instruction i -> row 16w + 4i + (lane >> 4)
+  const int lrow = lane >> 4, lpos = lane & 15;
+  int pn[4], poh[4], pow_[4];  // pixel coordinates of this lane's 4 rows (advanced by 64 pixels per step)
+  long long pm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long m = p_begin + w * 16 + i * 4 + lrow;
+    pm[i] = m;
+    long long mm = m < g.M ? m : 0;
+    int n = (int)(mm / ((long long)g.OH * g.OW));
+    int rem = (int)(mm - (long long)n * g.OH * g.OW);
+    pn[i] = n;
+    poh[i] = rem / g.OW;
+    pow_[i] = rem - poh[i] * g.OW;
+  }
+  __syncthreads();
+
+  auto stage = [&](int buf) {
+    unsigned char *dG = sG + buf * T_BYTES + (w * 16) * 256, *dX = sX + buf * T_BYTES + (w * 16) * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = w * 16 + i * 4 + lrow;
+      const int c = lpos ^ tr_swz(r);
+      const bool rok = pm[i] < p_end;
+      // dy piece
+      const int co = co0 + c * 8;
+      const bf16_t *sg = (rok && co < wg.Cout) ? dy + ((size_t)pm[i] * wg.ldg + co) : (const bf16_t *)g_zero_page;
+      glds16(sg, dG + i * 1024);
+      // gathered activation piece
+      const int q = q0 + c;
+      const bf16_t *sx = (const bf16_t *)g_zero_page;
+      if (q < g.nq) sx = piece_src(x, g, rok, pn[i] * g.H * g.W, poh[i] * g.stride - g.pad, pow_[i] * g.stride - g.pad, taps[q]);
+      glds16(sx, dX + i * 1024);
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pm[i] += BP;
+      pow_[i] += BP;
+      while (pow_[i] >= g.OW) { pow_[i] -= g.OW; ++poh[i]; }
+      while (poh[i] >= g.OH) { poh[i] -= g.OH; ++pn[i]; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // transposing-read addresses: wave tile = 64 co (wm) x 64 k columns (wn); a 16-lane group reads a 4-row x 16-column block
+  const int wm = w >> 1, wn = w & 1;
+  const int grp = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3, lh = lane >> 5;
+  // row inside a 16-pixel k-step: 8*lh + 4*half + tq ; column piece: (colbase >> 3) + 2*grp + (tp >> 1) ; + 8*(tp & 1) bytes
+  int addrG[2][2], addrX[2][2];  // [tile 0/1][half], for ks = 0; further k-steps add 16 rows (swizzle repeats every 16 rows)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int r = 8 * lh + 4 * half + tq;
+      const int cg = ((wm * 64 + j * 32) >> 3) + 2 * grp + (tp >> 1);
+      const int cx = ((wn * 64 + j * 32) >> 3) + 2 * grp + (tp >> 1);
+      addrG[j][half] = r * 256 + ((cg ^ tr_swz(r)) << 4) + 8 * (tp & 1);
+      addrX[j][half] = r * 256 + ((cx ^ tr_swz(r)) << 4) + 8 * (tp & 1);
+    }
+
+  if (nsteps > 0) stage(0);
+  for (int t = 0; t < nsteps; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nsteps) { advance(); stage(buf ^ 1); }
+    const unsigned char *pG = sG + buf * T_BYTES, *pX = sX + buf * T_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + addrG[j][0]));
+        short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + addrG[j][1]));
+        short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + addrX[j][0]));
+        short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + addrX[j][1]));
+        typedef __attribute__((ext_vector_type(8))) short short8_t;
+        short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        a[j] = __builtin_bit_cast(bf16x8, av);
+        b[j] = __builtin_bit_cast(bf16x8, bv);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // partial slab [split][Cout][Ktot] (fp32): rows = co, lanes = k columns (contiguous)
+  const int Ktot = g.nq * 8;
+  float *out = slab + (size_t)split * wg.Cout * Ktot;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = q0 * 8 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < wg.Cout && col < Ktot) out[(size_t)co * Ktot + col] = acc[i][j][r];
+      }
+    }
+}
+
+// dW = sum over splits (fixed order), written as fp32 or bf16
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ slab, int splits, long long total,
+                                                                void *__restrict__ dw, int out_bf16) {
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i + 4 <= total) {
+    for (int k = 0; k < splits; ++k) {
+      float4 v = *(const float4 *)(slab + (size_t)k * total + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (out_bf16) {
+      uint2 o;
+      o.x = rne_bf16(s.x) | (rne_bf16(s.y) << 16);
+      o.y = rne_bf16(s.z) | (rne_bf16(s.w) << 16);
+      *(uint2 *)((bf16_t *)dw + i) = o;
+    } else *(float4 *)((float *)dw + i) = s;
+  } else {
+    for (long long e = i; e < total; ++e) {
+      float a = 0.f;
+      for (int k = 0; k < splits; ++k) a += slab[(size_t)k * total + e];
+      if (out_bf16) ((bf16_t *)dw)[e] = (bf16_t)rne_bf16(a);
+      else ((float *)dw)[e] = a;
+    }
+  }
+}
+
+// Wt'[ci][kh][kw][co] = W[co][kh][kw][ci]  (the dgrad's B^T operand)
+__global__ __launch_bounds__(256) void conv_weight_transpose_kernel(const bf16_t *__restrict__ w, bf16_t *__restrict__ wt,
+                                                                    int Cout, int taps, int Cin) {
+  __shared__ bf16_t tile[32][33];
+  const int tap = blockIdx.z, c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    int co = o0 + r, ci = c0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * taps + tap) * Cin + ci] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int ci = c0 + r, co = o0 + tx;
+    if (ci < Cin && co < Cout) wt[((size_t)ci * taps + tap) * Cout + co] = tile[tx][r];
+  }
+}
+
+bool geom_ok(int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil) {
+  return N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C < 65536 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dil > 0 &&
+         (KH - 1) * dil < 256 && (KW - 1) * dil < 256 && (long long)KH * KW * C / 8 <= 8192;
+}
+
+size_t igemm_lds_bytes(int WN, int nq) { return (size_t)2 * 128 * 128 + (size_t)2 * WN * 64 * 128 + (size_t)nq * 4; }
+
+}  // namespace
+}  // namespace bfhip
+
+using namespace bfhip;
+
+BFHIP_EXPORT int bfhip_conv2d_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
+  return geom_ok(N, H, W, Cin, KH, KW, stride, pad, dil) && Cout > 0 && Cout % 8 == 0 ? 1 : 0;
+}
+
+// rows of the BN-statistics partial buffer the forward writes: stat_partial f32[conv2d_stat_rows][2][Cout]
+BFHIP_EXPORT int bfhip_conv2d_stat_rows(int N, int OH, int OW) { return ceil_div((long long)N * OH * OW, 128); }
+
+static int launch_igemm(const void *x, const void *wt, const float *bias, void *y, float *stat_partial, ConvGeom g, int out_f32,
+                        hipStream_t s, const char *what) {
+  const int WN = g.Kout > 64 ? 2 : 1;
+  const int tiles_m = ceil_div(g.M, 128), tiles_n = ceil_div(g.Kout, WN * 64);
+  const size_t lds = igemm_lds_bytes(WN, g.nq);
+  dim3 grid((unsigned)((long long)tiles_m * tiles_n));
+#define BFHIP_IG(WNV, F32)                                                                                              \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<WNV, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2); \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_igemm_kernel<WNV, F32>), grid, dim3(256), lds, s, (const bf16_t *)x, (const bf16_t *)wt, bias, y, \
+                       stat_partial, g, tiles_m, tiles_n);                                                             \
+  } while (0)
+  if (WN == 2) { if (out_f32) BFHIP_IG(2, true); else BFHIP_IG(2, false); }
+  else { if (out_f32) BFHIP_IG(1, true); else BFHIP_IG(1, false); }
+#undef BFHIP_IG
+  return check_launch(what);
+}
+
+// y[N, OH, OW, Cout] (pixel pitch ldy) = conv(x[N, H, W, Cin] (pixel pitch ldx), w[Cout][KH][KW][Cin]) (+ bias); bf16 in,
+// bf16 or fp32 out.  stat_partial (optional): f32[ceil(M / 128)][2][Cout] per-row-block column sums / sums of squares of the
+// un-biased fp32 accumulators (the `partial` input of bfhip_bn2d_fwd_partials).
+BFHIP_EXPORT int bfhip_conv2d_fwd(const void *x, int ldx, const void *w, const float *bias, void *y, int ldy, int N, int H, int W,
+                                  int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32,
+                                  float *stat_partial, void *stream_) {
+  BFHIP_REQUIRE(bfhip_conv2d_supported(N, H, W, Cin, Cout, KH, KW, stride, pad, dil), "conv2d_fwd: unsupported geometry");
+  BFHIP_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+  BFHIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ldx % 8 == 0 && ldx >= Cin && ldy >= Cout,
+                "conv2d_fwd: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
+  ConvGeom g;
+  g.N = N; g.H = H; g.W = W; g.C = Cin; g.ldx = ldx;
+  g.OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  g.OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  BFHIP_REQUIRE(g.OH > 0 && g.OW > 0, "conv2d_fwd: empty output");
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 0;
+  g.nq = KH * KW * Cin / 8;
+  g.M = (long long)N * g.OH * g.OW;
+  g.Kout = Cout; g.ldw = KH * KW * Cin; g.ldy = ldy;
+  return launch_igemm(x, w, bias, y, stat_partial, g, out_f32, (hipStream_t)stream_, "conv2d_fwd");
+}
+
+BFHIP_EXPORT size_t bfhip_conv2d_dgrad_workspace_bytes(int Cin, int Cout, int KH, int KW) {
+  return align_up((size_t)Cin * KH * KW * Cout * 2, 256);
+}
+
+// dx[N, H, W, Cin] = conv_transpose(dy[N, OH, OW, Cout], w): the forward kernel in transposed-gather mode over the
+// [Cin][KH][KW][Cout] transpose of the weight (built in `workspace`).
+BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace,
+                                    size_t workspace_bytes, void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  BFHIP_REQUIRE(bfhip_conv2d_supported(N, H, W, Cin, Cout, KH, KW, stride, pad, dil), "conv2d_dgrad: unsupported geometry");
+  BFHIP_REQUIRE(dy && w && dx && workspace, "conv2d_dgrad: null pointer");
+  BFHIP_REQUIRE(workspace_bytes >= bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), "conv2d_dgrad: workspace too small");
+  BFHIP_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)workspace % 16) == 0 && ldg % 8 == 0 && ldg >= Cout && ldx >= Cin,
+                "conv2d_dgrad: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
+  const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW), dim3(256), 0, s,
+                     (const bf16_t *)w, (bf16_t *)workspace, Cout, KH * KW, Cin);
+  ConvGeom g;
+  g.N = N; g.H = OH; g.W = OW; g.C = Cout; g.ldx = ldg;   // gathered tensor = dy
+  g.OH = H; g.OW = W;                                    // GEMM rows = input pixels
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 1;
+  g.nq = KH * KW * Cout / 8;
+  g.M = (long long)N * H * W;
+  g.Kout = Cin; g.ldw = KH * KW * Cout; g.ldy = ldx;
+  return launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad");
+}
+
+static void wgrad_plan(long long M, int Cout, int Ktot, int *splits, long long *rows_per_split, int *tiles_co, int *tiles_k) {
+  *tiles_co = ceil_div(Cout, 128);
+  *tiles_k = ceil_div(Ktot, 128);
+  const int tiles = *tiles_co * *tiles_k;
+  long long steps = (M + 63) / 64;
+  int want = (512 + tiles - 1) / tiles;             // two workgroups per CU: each split costs a full fp32 slab of dW
+  if (want > steps / 8) want = (int)(steps / 8);    // at least 8 K-steps per workgroup
+  if (want < 1) want = 1;
+  long long per = (steps + want - 1) / want;
+  *splits = (int)((steps + per - 1) / per);
+  *rows_per_split = per * 64;
+}
+
+BFHIP_EXPORT size_t bfhip_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
+  int splits, tco, tk;
+  long long rps;
+  wgrad_plan((long long)N * OH * OW, Cout, KH * KW * Cin, &splits, &rps, &tco, &tk);
+  return align_up((size_t)splits * Cout * KH * KW * Cin * sizeof(float), 256);
+}
+
+// dw[Cout][KH][KW][Cin] (fp32 or bf16) = sum over pixels of dy x gathered x
+BFHIP_EXPORT int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw, int N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, int dil, int dw_bf16, void *workspace,
+                                    size_t workspace_bytes, void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  BFHIP_REQUIRE(bfhip_conv2d_supported(N, H, W, Cin, Cout, KH, KW, stride, pad, dil), "conv2d_wgrad: unsupported geometry");
+  BFHIP_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: null pointer");
+  BFHIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ldx % 8 == 0 && ldg % 8 == 0 && ldx >= Cin && ldg >= Cout,
+                "conv2d_wgrad: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
+  WgradGeom wg;
+  ConvGeom &g = wg.c;
+  g.N = N; g.H = H; g.W = W; g.C = Cin; g.ldx = ldx;
+  g.OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  g.OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 0;
+  g.nq = KH * KW * Cin / 8;
+  g.M = (long long)N * g.OH * g.OW;
+  g.Kout = Cout; g.ldw = 0; g.ldy = 0;
+  wg.Cout = Cout; wg.ldg = ldg;
+  wgrad_plan(g.M, Cout, KH * KW * Cin, &wg.splits, &wg.rows_per_split, &wg.tiles_co, &wg.tiles_k);
+  BFHIP_REQUIRE(workspace_bytes >= bfhip_conv2d_wgrad_workspace_bytes(N, g.OH, g.OW, Cin, Cout, KH, KW), "conv2d_wgrad: workspace too small");
+  const size_t lds = (size_t)4 * 64 * 256 + (size_t)g.nq * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)wg.tiles_co * wg.tiles_k * wg.splits)), dim3(256), lds, s,
+                     (const bf16_t *)x, (const bf16_t *)dy, (float *)workspace, wg);
+  const long long total = (long long)Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(total, 1024)), dim3(256), 0, s, (const float *)workspace, wg.splits,
+                     total, dw, dw_bf16);
+  return check_launch("conv2d_wgrad");
+}

@@ -192,6 +192,14 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *__restrict__
   __syncthreads();
   const double INF = __longlong_as_double(0x7ff0000000000000LL);
   int err = 0;
+  {  // scipy's linear_sum_assignment rejects a matrix with ANY NaN or -inf entry ("matrix contains invalid numeric entries")
+    int bad = 0;
+    for (int e = lane; e < P * g; e += 64) {
+      const float c = Cb[(size_t)(e / g) * G + (e % g)];
+      bad |= (c != c) || (c == -__builtin_inff());
+    }
+    err = __any(bad) ? 1 : 0;
+  }
   for (int cur = 0; cur < nr && !err; ++cur) {
     for (int j = lane; j < nc; j += 64) { spc[j] = INF; SC[j] = 0; }
     for (int i = lane; i < nr; i += 64) SR[i] = 0;

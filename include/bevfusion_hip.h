@@ -419,6 +419,32 @@ int bfhip_query_losses(const float *cls_logits, const int32_t *labels, const flo
                        const float *code_weights, int B, int C, int P, int K, int ld, int p_off, float gamma,
                        float alpha, float *grad_cls, float *grad_box, float *loss_sums, void *stream);
 
+/* ---- dense 2-D convolution, channels-last bf16, implicit GEMM on the matrix cores (csrc/conv2d.hip).
+ * Replaces the cuDNN convolutions behind torch.nn.Conv2d of ConvFuser (projects/BEVFusion/bevfusion/bevfusion_head.py:26-38),
+ * SECOND / SECONDFPN (mmdet3d/models/backbones/second.py:27-95, necks/second_fpn.py:30-94), shared_conv (:95-102),
+ * depthnet / downsample (projects/BEVFusion/bevfusion/depth_lss.py:592-620) and GeneralizedLSSFPN
+ * (projects/BEVFusion/bevfusion/bevfusion_necks.py:50-72).  x bf16 [N,H,W,Cin] with pixel pitch ldx, w bf16
+ * [Cout][KH][KW][Cin] (the memory of a channels-last Conv2d weight), y bf16|f32 [N,OH,OW,Cout] with pixel pitch ldy; Cin, Cout
+ * multiples of 8.  stat_partial (optional) f32[bfhip_conv2d_stat_rows()][2][Cout]: per-row-block column sums and sums of
+ * squares of the fp32 accumulators (without bias) = the `partial` input of bfhip_bn2d_fwd_partials. */
+int bfhip_conv2d_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil);
+int bfhip_conv2d_stat_rows(int N, int OH, int OW);
+int bfhip_conv2d_fwd(const void *x, int ldx, const void *w, const float *bias, void *y, int ldy, int N, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, float *stat_partial, void *stream);
+size_t bfhip_conv2d_dgrad_workspace_bytes(int Cin, int Cout, int KH, int KW);
+int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin, int Cout,
+                       int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace, size_t workspace_bytes,
+                       void *stream);
+size_t bfhip_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
+int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw, int N, int H, int W, int Cin, int Cout,
+                       int KH, int KW, int stride, int pad, int dil, int dw_bf16, void *workspace, size_t workspace_bytes,
+                       void *stream);
+/* BatchNorm2d forward whose statistics pass already happened in the producing convolution's epilogue: `partial`
+ * f32[nblk][2][C] (column sums, sums of squares per row block).  Otherwise as bfhip_bn2d_fwd. */
+int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
+                            int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
+                            float *stats, void *y, const float *partial, int nblk, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,175 @@
+"""GPU parity of csrc/conv2d.hip (implicit-GEMM convolution on the matrix cores: forward, data gradient, weight gradient,
+BatchNorm statistics in the epilogue) through the C ABI against torch's fp32 convolution on the CPU.
+
+Inputs are rounded to bf16 first, so the oracle sees exactly the operands the kernel sees: what remains is fp32
+accumulation order (<= 1e-4 rel, checked on the fp32 outputs: weight gradient, statistics, fp32 forward) and the final
+rounding of bf16 outputs (<= 2^-8 rel per element; north star: 1e-2 rel for bf16 features).  No ReLU anywhere: these are
+the mask-free gradient checks the module-level tests refer to."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import bevfusion_amd  # noqa: F401
+from bevfusion_amd import _lib
+from bevfusion_amd.conv2d import Conv2d, conv2d
+
+pytestmark = pytest.mark.gpu
+
+#        N   H   W  Cin Cout k  s  p  d  bias
+GEOMS = [(2, 45, 52, 336, 256, 3, 1, 1, 1, False),   # ConvFuser (BF/bevfusion_head.py:26-38), odd extents
+         (2, 45, 52, 128, 128, 3, 1, 1, 1, False),   # SECOND block 1
+         (2, 44, 52, 128, 256, 3, 2, 1, 1, False),   # SECOND block 2 entry, stride 2
+         (2, 45, 52, 512, 128, 3, 1, 1, 1, True),    # shared_conv (bias)
+         (3, 32, 88, 320, 256, 3, 1, 1, 1, True),    # depthnet conv 1
+         (3, 32, 88, 256, 200, 1, 1, 0, 1, True),    # 1x1 projection, Cout not a multiple of 64
+         (2, 90, 92, 80, 80, 3, 2, 1, 1, False),     # downsample, stride 2, Cin = 80 (K pieces straddle taps)
+         (2, 47, 33, 32, 64, 5, 2, 2, 1, True),      # dtransform 5x5 stride 2
+         (2, 33, 47, 8, 32, 5, 4, 2, 1, True),       # dtransform 5x5 stride 4, 8 input channels
+         (1, 20, 24, 64, 64, 3, 1, 2, 2, False),     # dilation 2
+         (2, 32, 88, 768, 256, 1, 1, 0, 1, False),   # LSS-FPN lateral 1x1
+         (1, 7, 9, 16, 24, 3, 1, 1, 1, False)]       # a single partial tile
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float()
+
+
+def _case(g, seed):
+    N, H, W, Cin, Cout, k, s, p, d, bias = g
+    rng = np.random.default_rng(seed)
+    x = _bf16_round(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)) if bias else None
+    return x, w, b
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def _l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("g", GEOMS, ids=lambda g: "x".join(str(v) for v in g[:9]))
+def test_forward_backward_vs_torch_cpu(dev, g):
+    N, H, W, Cin, Cout, k, s, p, d, bias = g
+    x, w, b = _case(g, seed=sum(g[:9]))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if b is not None else None
+    ref = F.conv2d(xr, wr, br, stride=s, padding=p, dilation=d)
+    gy = _bf16_round(np.random.default_rng(7).standard_normal(tuple(ref.shape)).astype(np.float32))
+    ref.backward(gy)
+    xg = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)      # fp32 master-less weights
+    bg = b.to(dev).requires_grad_(True) if b is not None else None
+    y, partial = conv2d(xg, wg, bg, s, p, d, emit_stats=b is None)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    assert _rel(y.float().cpu(), ref.detach()) < 1e-2 and _l2(y.float().cpu(), ref.detach()) < 4e-3
+    if partial is not None:  # BatchNorm statistics of the fp32 accumulators
+        M = N * ref.shape[2] * ref.shape[3]
+        assert partial.shape == ((M + 127) // 128, 2, Cout)
+        s0, s1 = partial[:, 0].double().sum(0).cpu(), partial[:, 1].double().sum(0).cpu()
+        r = ref.detach().double()
+        assert torch.allclose(s0, r.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * float(r.abs().max()))
+        assert torch.allclose(s1, (r * r).sum((0, 2, 3)), rtol=1e-4)
+    y.backward(gy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert _rel(xg.grad.float().cpu(), xr.grad) < 1e-2 and _l2(xg.grad.float().cpu(), xr.grad) < 4e-3
+    assert wg.grad.dtype == torch.float32 and _rel(wg.grad.cpu(), wr.grad) < 1e-4        # fp32 accumulate, fp32 out
+    if b is not None:
+        assert _rel(bg.grad.cpu(), br.grad) < 1e-4
+
+
+def test_fp32_output_is_exact_on_integer_data(dev):
+    """Integer-valued operands: every product and partial sum is exact in fp32, so the fp32-output forward / dgrad and the
+    weight gradient must equal torch's CPU result bit for bit -- whatever the summation order.  Catches any misplaced
+    tap, row or swizzle that a tolerance could hide."""
+    N, H, W, Cin, Cout, k, s, p, d = 2, 19, 23, 40, 72, 3, 2, 1, 1
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.integers(-3, 4, (N, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy(rng.integers(-2, 3, (Cout, Cin, k, k)).astype(np.float32))
+    ref = F.conv2d(x, w, None, stride=s, padding=p, dilation=d)
+    OH, OW = ref.shape[2:]
+    gy = torch.from_numpy(rng.integers(-2, 3, tuple(ref.shape)).astype(np.float32))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=s, padding=p, dilation=d).backward(gy)
+    xd = x.to(dev).to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+    wd = w.to(dev).to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+    gd = gy.to(dev).to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+    y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=dev)
+    st = _lib.stream_of(xd)
+    _lib.call("bfhip_conv2d_fwd", xd.data_ptr(), Cin, wd.data_ptr(), None, y.data_ptr(), Cout, N, H, W, Cin, Cout, k, k, s, p, d, 1,
+              None, st)
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
+    lib = _lib.load()
+    ws = torch.empty(max(lib.bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, k, k),
+                         lib.bfhip_conv2d_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, k, k)), dtype=torch.uint8, device=dev)
+    dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dev)
+    _lib.call("bfhip_conv2d_dgrad", gd.data_ptr(), Cout, wd.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Cout, k, k, s, p, d, 1,
+              ws.data_ptr(), ws.numel(), st)
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2), xr.grad)
+    dw = torch.empty((Cout, k, k, Cin), dtype=torch.float32, device=dev)
+    _lib.call("bfhip_conv2d_wgrad", xd.data_ptr(), Cin, gd.data_ptr(), Cout, dw.data_ptr(), N, H, W, Cin, Cout, k, k, s, p, d, 0,
+              ws.data_ptr(), ws.numel(), st)
+    assert torch.equal(dw.cpu().permute(0, 3, 1, 2), wr.grad)
+
+
+def test_channel_slice_input_and_bf16_weights(dev):
+    """A channel slice of a wider channels-last tensor is consumed in place (pixel pitch > C); bf16 parameters get bf16
+    weight gradients (the master-weight optimizer's layout)."""
+    rng = np.random.default_rng(5)
+    wide = torch.from_numpy(rng.standard_normal((2, 96, 30, 34)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    wide = wide.contiguous(memory_format=torch.channels_last)
+    xs = wide[:, 16:80]
+    conv = Conv2d(64, 64, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    conv.weight.data = conv.weight.data.to(torch.bfloat16)
+    conv.train()
+    assert conv.hip_eligible(xs)
+    y = conv(xs)
+    assert getattr(y, "_bfhip_stat_partial", None) is not None
+    ref = F.conv2d(xs.float().cpu(), conv.weight.detach().float().cpu(), padding=1)
+    assert _l2(y.float().cpu(), ref) < 4e-3
+    y.float().square().mean().backward()
+    assert conv.weight.grad.dtype == torch.bfloat16 and conv.weight.grad.shape == conv.weight.shape
+
+
+def test_module_falls_back_outside_its_domain(dev):
+    conv = Conv2d(16, 24, 3, padding=1).to(dev)
+    x32 = torch.randn(1, 16, 64, 64, device=dev)
+    assert not conv.hip_eligible(x32)                       # fp32 without autocast: the library's fp32 convolution
+    assert conv(x32).dtype == torch.float32
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert conv.hip_eligible(x32)
+        y = conv(x32)
+    assert y.dtype == torch.bfloat16
+    assert _l2(y.float().cpu(), F.conv2d(x32.cpu(), conv.weight.detach().cpu(), conv.bias.detach().cpu(), padding=1)) < 1e-2
+    odd = Conv2d(12, 24, 3, padding=1).to(dev)               # 12 input channels: not a multiple of 8
+    assert not odd.hip_eligible(torch.randn(1, 12, 64, 64, device=dev, dtype=torch.bfloat16))
+    grouped = Conv2d(16, 16, 3, padding=1, groups=2).to(dev)
+    assert not grouped.hip_eligible(torch.randn(1, 16, 64, 64, device=dev, dtype=torch.bfloat16))
+
+
+def test_conv_bn_relu_fused_statistics_match_unfused(dev):
+    """conv -> BatchNorm2dAct with the statistics taken from the conv epilogue equals the same layers with the
+    BatchNorm computing its own statistics pass (same kernels otherwise): outputs, running stats, gradients."""
+    from bevfusion_amd.bn2d import BatchNorm2dAct
+    torch.manual_seed(0)
+    conv = Conv2d(64, 128, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last).train()
+    res = []
+    x0 = torch.randn(2, 64, 45, 52, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    for fused in (True, False):
+        bn = BatchNorm2dAct(128, act=True).to(dev).train()
+        x = x0.clone().requires_grad_(True)
+        conv.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+            assert hasattr(y, "_bfhip_stat_partial")
+            if not fused:
+                del y._bfhip_stat_partial
+            out = bn(y)
+        out.float().square().mean().backward()
+        res.append((out.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.float(), conv.weight.grad.clone()))
+    for a, b in zip(*res):
+        assert _l2(a, b) < 3e-3, _l2(a, b)   # statistics from fp32 accumulators vs from the bf16-rounded tensor

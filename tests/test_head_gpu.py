@@ -131,6 +131,14 @@ def test_hungarian_flags_non_finite_costs(dev):
     assigned, status = ht.hungarian(cost, torch.tensor([4, 4], dtype=torch.int32, device=dev))
     assert status.cpu().tolist() == [1, 0]
     assert (assigned[0] == 0).all() and (assigned[1] > 0).sum() == 4
+    # a single invalid entry is enough (scipy: "matrix contains invalid numeric entries"), +inf alone is a valid (forbidden) pair
+    cost = torch.rand(3, 8, 4, device=dev)
+    cost[0, 5, 2] = float("nan")
+    cost[1, 1, 0] = float("-inf")
+    cost[2, 3, 3] = float("inf")
+    assigned, status = ht.hungarian(cost, torch.tensor([4, 4, 4], dtype=torch.int32, device=dev))
+    assert status.cpu().tolist() == [1, 1, 0]
+    assert (assigned[2] > 0).sum() == 4 and assigned[2, 3] != 4
 
 
 def test_targets_match_oracle(dev):

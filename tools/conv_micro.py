@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Per-layer timing of csrc/conv2d.hip against the library convolution (MIOpen / CK through torch) it replaces, at the
+batch-4 shapes of the `full` workload.  One process, interleaved rounds, HIP events.  Prints one JSON object."""
+import importlib.util as ilu
+import json
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+spec = ilu.spec_from_file_location("_t", os.path.join(ROOT, "bevfusion-3d_object_detection_amd", "tuning", "__init__.py"))
+mod = ilu.module_from_spec(spec)
+spec.loader.exec_module(mod)
+mod.use_shipped_miopen_db()
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import bevfusion_amd  # noqa: E402,F401
+from bevfusion_amd.conv2d import conv2d  # noqa: E402
+
+#          name                 N   H    W    Cin  Cout k s p
+LAYERS = [("ConvFuser",          4, 180, 180, 336, 256, 3, 1, 1),
+          ("SECOND.b1.conv0",    4, 180, 180, 256, 128, 3, 1, 1),
+          ("SECOND.b1.conv1-5",  4, 180, 180, 128, 128, 3, 1, 1),
+          ("SECOND.b2.conv0",    4, 180, 180, 128, 256, 3, 2, 1),
+          ("SECOND.b2.conv1-5",  4, 90, 90, 256, 256, 3, 1, 1),
+          ("SECONDFPN.1x1",      4, 180, 180, 128, 256, 1, 1, 0),
+          ("shared_conv",        4, 180, 180, 512, 128, 3, 1, 1),
+          ("depthnet.0",         24, 32, 88, 320, 256, 3, 1, 1),
+          ("depthnet.1",         24, 32, 88, 256, 256, 3, 1, 1),
+          ("downsample.0",       4, 360, 360, 80, 80, 3, 1, 1),
+          ("downsample.1",       4, 360, 360, 80, 80, 3, 2, 1),
+          ("lssfpn.lateral0",    24, 32, 88, 768, 256, 1, 1, 0),
+          ("lssfpn.fpn0",        24, 32, 88, 256, 256, 3, 1, 1),
+          ("resnet.l2.3x3",      24, 32, 88, 128, 128, 3, 1, 1),
+          ("resnet.l1.1x1",      24, 64, 176, 64, 256, 1, 1, 0),
+          ("resnet.l3.1x1",      24, 16, 44, 1024, 256, 1, 1, 0)]
+
+
+def timed(fn, iters):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    dev = torch.device("cuda:0")
+    only = sys.argv[1:] or None
+    out = []
+    for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
+        if only and not any(o in name for o in only):
+            continue
+        x = torch.randn(N, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        w.requires_grad_(True)
+        y0 = F.conv2d(x, w, None, s, p)
+        gy = torch.randn_like(y0)
+
+        def lib_fwd():
+            return F.conv2d(x, w, None, s, p)
+
+        def hip_fwd():
+            return conv2d(x, w, None, s, p, 1, True)[0]
+
+        def lib_bwd():
+            y = F.conv2d(x, w, None, s, p)
+            torch.autograd.grad(y, (x, w), gy)
+
+        def hip_bwd():
+            y = conv2d(x, w, None, s, p, 1, True)[0]
+            torch.autograd.grad(y, (x, w), gy)
+
+        for f in (lib_fwd, hip_fwd, lib_bwd, hip_bwd):
+            for _ in range(3):
+                f()
+        torch.cuda.synchronize()
+        rounds = {"lib_fwd": [], "hip_fwd": [], "lib_fb": [], "hip_fb": []}
+        for _ in range(3):
+            rounds["lib_fwd"].append(timed(lib_fwd, 10))
+            rounds["hip_fwd"].append(timed(hip_fwd, 10))
+            rounds["lib_fb"].append(timed(lib_bwd, 10))
+            rounds["hip_fb"].append(timed(hip_bwd, 10))
+        OH, OW = y0.shape[2:]
+        gflop = 2.0 * N * OH * OW * Cout * Cin * k * k / 1e9
+        r = {kk: round(min(v), 4) for kk, v in rounds.items()}
+        r.update(layer=name, gflop_fwd=round(gflop, 2),
+                 hip_fwd_tflops=round(gflop / r["hip_fwd"], 1), lib_fwd_tflops=round(gflop / r["lib_fwd"], 1),
+                 hip_bwd_ms=round(r["hip_fb"] - r["hip_fwd"], 4), lib_bwd_ms=round(r["lib_fb"] - r["lib_fwd"], 4),
+                 hip_bwd_tflops=round(2 * gflop / max(r["hip_fb"] - r["hip_fwd"], 1e-6), 1),
+                 lib_bwd_tflops=round(2 * gflop / max(r["lib_fb"] - r["lib_fwd"], 1e-6), 1))
+        out.append(r)
+        print(json.dumps(r), flush=True)
+    print(json.dumps({"layers": out}))
+
+
+if __name__ == "__main__":
+    main()
