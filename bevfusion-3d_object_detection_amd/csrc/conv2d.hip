@@ -304,21 +304,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
   }
   __syncthreads();
 
+  // a lane's pieces are fixed for the whole kernel: dy channel block / K piece (tap, ci) of row i
+  int pdh[4], pdw[4], pcx[4];
+  bool qok[4], cok[4];
+  const bf16_t *gsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = w * 16 + i * 4 + lrow;
+    const int c = lpos ^ tr_swz(r);
+    const int co = co0 + c * 8, q = q0 + c;
+    cok[i] = co < wg.Cout;
+    qok[i] = q < g.nq;
+    const unsigned info = qok[i] ? taps[q] : 0u;
+    pdh[i] = info >> 24;
+    pdw[i] = (info >> 16) & 0xff;
+    pcx[i] = info & 0xffff;
+    gsrc[i] = dy + ((size_t)pm[i] * wg.ldg + co);
+  }
   auto stage = [&](int buf) {
     unsigned char *dG = sG + buf * T_BYTES + (w * 16) * 256, *dX = sX + buf * T_BYTES + (w * 16) * 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = w * 16 + i * 4 + lrow;
-      const int c = lpos ^ tr_swz(r);
       const bool rok = pm[i] < p_end;
-      // dy piece
-      const int co = co0 + c * 8;
-      const bf16_t *sg = (rok && co < wg.Cout) ? dy + ((size_t)pm[i] * wg.ldg + co) : (const bf16_t *)g_zero_page;
-      glds16(sg, dG + i * 1024);
-      // gathered activation piece
-      const int q = q0 + c;
-      const bf16_t *sx = (const bf16_t *)g_zero_page;
-      if (q < g.nq) sx = piece_src(x, g, rok, pn[i] * g.H * g.W, poh[i] * g.stride - g.pad, pow_[i] * g.stride - g.pad, taps[q]);
+      glds16((rok && cok[i]) ? gsrc[i] : (const bf16_t *)g_zero_page, dG + i * 1024);
+      const int ih = poh[i] * g.stride - g.pad + pdh[i], iw = pow_[i] * g.stride - g.pad + pdw[i];
+      const bool ok = rok && qok[i] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      const bf16_t *sx = ok ? x + ((size_t)((pn[i] * g.H + ih) * g.W + iw) * g.ldx + pcx[i]) : (const bf16_t *)g_zero_page;
       glds16(sx, dX + i * 1024);
     }
   };
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       pm[i] += BP;
+      gsrc[i] += (size_t)BP * wg.ldg;
       pow_[i] += BP;
       while (pow_[i] >= g.OW) { pow_[i] -= g.OW; ++poh[i]; }
       while (poh[i] >= g.OH) { poh[i] -= g.OH; ++pn[i]; }
@@ -536,12 +548,25 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
   return launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad");
 }
 
+static int resident_blocks() {  // workgroups the chip holds at once (2 per CU: 66 KB of LDS each)
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = 2 * v;
+    else { (void)hipGetLastError(); n = 512; }
+  }
+  return n;
+}
+
+// The launch must fit ONE residency round: every workgroup runs the same number of K-steps, so a grid of 513 workgroups on
+// 512 slots takes twice as long as one of 512 (measured: 130 vs 66 us on the 128 -> 128 layer).
 static void wgrad_plan(long long M, int Cout, int Ktot, int *splits, long long *rows_per_split, int *tiles_co, int *tiles_k) {
   *tiles_co = ceil_div(Cout, 128);
   *tiles_k = ceil_div(Ktot, 128);
   const int tiles = *tiles_co * *tiles_k;
   long long steps = (M + 63) / 64;
-  int want = (512 + tiles - 1) / tiles;             // two workgroups per CU: each split costs a full fp32 slab of dW
+  const int slots = resident_blocks();
+  int want = tiles >= slots ? 1 : slots / tiles;    // each split costs a full fp32 slab of dW
   if (want > steps / 8) want = (int)(steps / 8);    // at least 8 K-steps per workgroup
   if (want < 1) want = 1;
   long long per = (steps + want - 1) / want;

@@ -1,7 +1,9 @@
-"""Dense (MFMA-bound) modules of the BEVFusion graph, as plain torch.nn on ROCm (MIOpen / hipBLASLt).
+"""Dense (MFMA-bound) modules of the BEVFusion graph.
 
-These are consumers/producers of the hot-path operators, not the product: they exist so that the full
-fwd+bwd step of BASELINE.json configs 3-5 can run without mmcv/mmdet/mmengine (absent in this image).
+The BEV / view-transform / head convolutions (SURVEY 8 a-8 ... a-11) are `conv2d.Conv2d`: nn.Conv2d whose bf16 channels-last
+calls run the hand-written implicit-GEMM kernels of csrc/conv2d.hip (forward, dgrad, wgrad, BatchNorm statistics in the
+epilogue); the image backbone (ResNet-50, a consumer of the hot path, not a row of it) stays on torch.nn (MIOpen / CK).
+The modules exist so that the full fwd+bwd step of BASELINE.json configs 3-5 runs without mmcv/mmdet/mmengine (absent here).
 Layer shapes follow the reference:
   ResNet50            BASELINE.json's image backbone (the reference config uses mmdet Swin-T; any backbone
                       returning 3 levels works, BF/bevfusion.py:55,161-171)
@@ -19,6 +21,7 @@ from torch import nn
 
 from . import _lib
 from .bn2d import BatchNorm2dAct, BatchNormRows, bn_act
+from .conv2d import Conv2d
 from .linear_rows import linear_rows
 from . import attention as split_attention
 from .registry import MODELS
@@ -126,7 +129,7 @@ class ConvModule(nn.Module):
         super().__init__()
         bias = (not norm) if bias == "auto" else bool(bias)
         if dim == 2:
-            self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=bias)
+            self.conv = Conv2d(cin, cout, k, stride=stride, padding=padding, bias=bias)
             self.bn = BatchNorm2dAct(cout, eps=eps, momentum=momentum, act=act) if norm else None
         else:
             self.conv = nn.Conv1d(cin, cout, k, stride=stride, padding=padding, bias=bias)
@@ -195,7 +198,7 @@ class GeneralizedLSSFPN(nn.Module):
 class ConvFuser(nn.Sequential):
     def __init__(self, in_channels, out_channels):
         self.in_channels, self.out_channels = in_channels, out_channels
-        super().__init__(nn.Conv2d(sum(in_channels), out_channels, 3, padding=1, bias=False),
+        super().__init__(Conv2d(sum(in_channels), out_channels, 3, padding=1, bias=False),
                          *bn_act(out_channels))
 
     def forward(self, inputs):
@@ -212,10 +215,10 @@ class SECOND(nn.Module):
         in_filters = [in_channels, *out_channels[:-1]]
         blocks = []
         for i, n in enumerate(layer_nums):
-            block = [nn.Conv2d(in_filters[i], out_channels[i], 3, stride=layer_strides[i], padding=1, bias=False),
+            block = [Conv2d(in_filters[i], out_channels[i], 3, stride=layer_strides[i], padding=1, bias=False),
                      *bn_act(out_channels[i], eps=eps, momentum=mom)]
             for _ in range(n):
-                block += [nn.Conv2d(out_channels[i], out_channels[i], 3, padding=1, bias=False),
+                block += [Conv2d(out_channels[i], out_channels[i], 3, padding=1, bias=False),
                           *bn_act(out_channels[i], eps=eps, momentum=mom)]
             blocks.append(nn.Sequential(*block))
         self.blocks = nn.ModuleList(blocks)
@@ -242,7 +245,7 @@ class SECONDFPN(nn.Module):
                 up = nn.ConvTranspose2d(in_channels[i], oc, s, stride=s, bias=False)
             else:
                 k = int(round(1 / s))
-                up = nn.Conv2d(in_channels[i], oc, k, stride=k, bias=False)
+                up = Conv2d(in_channels[i], oc, k, stride=k, bias=False)
             deblocks.append(nn.Sequential(up, *bn_act(oc, eps=eps, momentum=mom)))
         self.deblocks = nn.ModuleList(deblocks)
 
@@ -386,9 +389,9 @@ class BEVFusionHead(nn.Module):
             self.bbox_coder = None
         self.num_classes, self.num_proposals = num_classes, num_proposals
         self.num_decoder_layers, self.nms_kernel_size, self.auxiliary = num_decoder_layers, nms_kernel_size, auxiliary
-        self.shared_conv = nn.Conv2d(in_channels, hidden_channel, 3, padding=1)
+        self.shared_conv = Conv2d(in_channels, hidden_channel, 3, padding=1)
         self.heatmap_head = nn.Sequential(ConvModule(hidden_channel, hidden_channel, 3, padding=1),
-                                          nn.Conv2d(hidden_channel, num_classes, 3, padding=1))
+                                          Conv2d(hidden_channel, num_classes, 3, padding=1))
         self.class_encoding = nn.Conv1d(num_classes, hidden_channel, 1)
         self.decoder = nn.ModuleList([TransformerDecoderLayer(**decoder_layer) for _ in range(num_decoder_layers)])
         heads = dict(common_heads)

@@ -21,6 +21,7 @@ from torch import nn
 
 from . import _lib
 from .bn2d import bn_act
+from .conv2d import Conv2d
 from .ops import bev_pool
 from .registry import MODELS
 
@@ -296,10 +297,10 @@ def _make_downsample(out_channels, downsample):
         return nn.Identity()
     assert downsample == 2, downsample
     return nn.Sequential(
-        nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), *bn_act(out_channels),
-        nn.Conv2d(out_channels, out_channels, 3, stride=downsample, padding=1, bias=False),
+        Conv2d(out_channels, out_channels, 3, padding=1, bias=False), *bn_act(out_channels),
+        Conv2d(out_channels, out_channels, 3, stride=downsample, padding=1, bias=False),
         *bn_act(out_channels),
-        nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), *bn_act(out_channels))
+        Conv2d(out_channels, out_channels, 3, padding=1, bias=False), *bn_act(out_channels))
 
 
 class BaseDepthTransform(BaseViewTransform):
@@ -392,12 +393,12 @@ class DepthLSSTransform(BaseDepthTransform):
         super().__init__(in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound)
         self.dtransform = nn.Sequential(
             nn.Conv2d(1, 8, 1), *bn_act(8),
-            nn.Conv2d(8, 32, 5, stride=4, padding=2), *bn_act(32),
-            nn.Conv2d(32, 64, 5, stride=2, padding=2), *bn_act(64))
+            Conv2d(8, 32, 5, stride=4, padding=2), *bn_act(32),
+            Conv2d(32, 64, 5, stride=2, padding=2), *bn_act(64))
         self.depthnet = nn.Sequential(
-            nn.Conv2d(in_channels + 64, in_channels, 3, padding=1), *bn_act(in_channels),
-            nn.Conv2d(in_channels, in_channels, 3, padding=1), *bn_act(in_channels),
-            nn.Conv2d(in_channels, self.D + self.C, 1))
+            Conv2d(in_channels + 64, in_channels, 3, padding=1), *bn_act(in_channels),
+            Conv2d(in_channels, in_channels, 3, padding=1), *bn_act(in_channels),
+            Conv2d(in_channels, self.D + self.C, 1))
         self.downsample = _make_downsample(out_channels, downsample)
 
     def run_dtransform(self, d):

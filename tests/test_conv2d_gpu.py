@@ -120,7 +120,7 @@ def test_channel_slice_input_and_bf16_weights(dev):
     """A channel slice of a wider channels-last tensor is consumed in place (pixel pitch > C); bf16 parameters get bf16
     weight gradients (the master-weight optimizer's layout)."""
     rng = np.random.default_rng(5)
-    wide = torch.from_numpy(rng.standard_normal((2, 96, 30, 34)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    wide = torch.from_numpy(rng.standard_normal((2, 96, 34, 36)).astype(np.float32)).to(dev).to(torch.bfloat16)
     wide = wide.contiguous(memory_format=torch.channels_last)
     xs = wide[:, 16:80]
     conv = Conv2d(64, 64, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)

@@ -136,8 +136,8 @@ class _HeadConvs(nn.Module):
 
     def __init__(self, cin, hidden, classes):
         super().__init__()
-        self.shared_conv = nn.Conv2d(cin, hidden, 3, padding=1)
-        self.heatmap_head = nn.Sequential(dm.ConvModule(hidden, hidden, 3, padding=1), nn.Conv2d(hidden, classes, 3, padding=1))
+        self.shared_conv = dm.Conv2d(cin, hidden, 3, padding=1)
+        self.heatmap_head = nn.Sequential(dm.ConvModule(hidden, hidden, 3, padding=1), dm.Conv2d(hidden, classes, 3, padding=1))
 
     def forward(self, x):
         f = self.shared_conv(x)
