@@ -56,22 +56,23 @@ SIGNATURES = {
     "bfhip_dynamic_scatter_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "bfhip_dynamic_scatter_bwd": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_voxel_mean": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "bfhip_voxel_compact_mean": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp] * 4),
     "bfhip_rasterise_depth_workspace_bytes": (_c_sz, [_c_int] * 3),
     "bfhip_rasterise_depth": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 4 + [_c_int] * 3 + [_c_vp, _c_vp] + [_c_int] * 3 +
                               [_c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_depth_histogram": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp, _c_vp, _c_vp, _c_vp]),
     "bfhip_bn1d_workspace_bytes": (_c_sz, [_c_int, _c_int]),
-    "bfhip_bn1d_fwd": (_c_int, [_c_vp] * 4 + [_c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] + [_c_vp] * 4 +
+    "bfhip_bn1d_fwd": (_c_int, [_c_vp] * 4 + [_c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] + [_c_vp] * 5 +
                        [_c_vp, _c_sz, _c_vp]),
-    "bfhip_bn1d_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 3 + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_bn1d_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 3 + [_c_vp] * 4 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_sparse_to_bev_nhwc": (_c_int, [_c_vp, _c_vp] + [_c_int] * 7 + [_c_vp, _c_vp]),
     "bfhip_bev_nhwc_to_sparse": (_c_int, [_c_vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_vp, _c_int,
                                           _c_int, _c_int, _c_vp, _c_vp]),
     "bfhip_bn2d_supported": (_c_int, [ctypes.c_longlong, _c_int, _c_int]),
     "bfhip_bn2d_workspace_bytes": (_c_sz, [ctypes.c_longlong, _c_int, _c_int]),
     "bfhip_bn2d_fwd": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +
-                       [_c_vp] * 4 + [_c_vp, _c_sz, _c_vp]),
-    "bfhip_bn2d_bwd": (_c_int, [_c_vp] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 3 + [_c_vp, _c_sz, _c_vp]),
+                       [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_bn2d_bwd": (_c_int, [_c_vp] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 4 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_xty_workspace_bytes": (_c_sz, [ctypes.c_longlong, _c_int, _c_int]),
     "bfhip_xty": (_c_int, [_c_vp, _c_vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_attn_workspace_bytes": (_c_sz, [_c_int] * 4),
@@ -100,7 +101,7 @@ SIGNATURES = {
     "bfhip_conv2d_wgrad_workspace_bytes": (_c_sz, [_c_int] * 7),
     "bfhip_conv2d_wgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_bn2d_fwd_partials": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +
-                                [_c_vp] * 4 + [_c_vp, _c_int, _c_vp]),
+                                [_c_vp] * 4 + [_c_vp, _c_int, _c_vp, _c_vp]),
     "bfhip_query_losses": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 4),
 }
 

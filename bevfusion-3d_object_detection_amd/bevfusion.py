@@ -7,6 +7,8 @@ Inputs follow the reference's `batch_inputs_dict` / metainfo contract (BF/bevfus
 """
 from typing import Dict, List, Optional
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -57,6 +59,11 @@ class BEVFusion(nn.Module):
         self.bbox_head = build(bbox_head)
         self.lidar_side_stream = False  # opt-in: run the LiDAR branch on a second HIP stream (bench.py enables it)
         self._side_stream = None
+        # static capacity mode of the LiDAR branch: buffers sized by (grow-only) bounds learnt from earlier frames, every row
+        # count on the device, ZERO host reads per forward; the first forward runs the exact path to learn them
+        self.static_lidar = os.environ.get("BFHIP_STATIC_LIDAR", "1") == "1"
+        self._voxel_cap = None
+        self._voxel_monitor = None
 
     # ------------------------------------------------------------------ LiDAR branch
     @torch.no_grad()
@@ -77,7 +84,9 @@ class BEVFusion(nn.Module):
                 voxel_layer.hard_voxelize_async(res, v, c, n, layer.voxel_size, layer.point_cloud_range,
                                                 layer.max_num_points, max_voxels, counts[k:k + 1])
                 bufs.append((v, c, n))
-            rets = [(v[:m], c[:m], n[:m]) for (v, c, n), m in zip(bufs, counts.tolist())]
+            ms = counts.tolist()
+            self._note_voxel_total(sum(ms))
+            rets = [(v[:m], c[:m], n[:m]) for (v, c, n), m in zip(bufs, ms)]
         else:
             rets = [layer(res) for res in points]
         for k, ret in enumerate(rets):
@@ -99,8 +108,57 @@ class BEVFusion(nn.Module):
                 feats = voxel_mean(feats, sizes)
         return feats, coords, sizes
 
+    def _note_voxel_total(self, total):
+        from .spconv import round_capacity
+        self._voxel_cap = max(self._voxel_cap or 0, round_capacity(total))
+
+    @torch.no_grad()
+    def voxelize_static(self, points: List[torch.Tensor]):
+        """voxelize() without host reads: one [B, max_voxels, ...] buffer set, per-sample voxelization with the counts left on
+        the device, then ONE kernel that builds the mean features and (b, x, y, z) coordinates of all samples in a
+        capacity-sized matrix whose active rows are the prefix (bfhip_voxel_compact_mean).  -> feats [cap, F],
+        coords i32[cap, 4] (inactive rows: b = -1), n_valid i32[1] on the device."""
+        from .spconv import CapacityMonitor
+        layer = self.pts_voxel_layer
+        B, dev = len(points), points[0].device
+        max_voxels = layer.max_voxels[0] if self.training else layer.max_voxels[1]
+        P, Fdim = layer.max_num_points, points[0].size(1)
+        if self._voxel_monitor is None:
+            self._voxel_monitor = CapacityMonitor()
+        seen = self._voxel_monitor.poll()
+        if seen is not None:
+            if seen[1] > self._voxel_cap:
+                import warnings
+                warnings.warn("voxelize_static: %d voxels exceeded the row capacity %d; capacity grown" % (seen[1], self._voxel_cap))
+            self._note_voxel_total(seen[1])
+        cap = self._voxel_cap
+        voxels = points[0].new_zeros((B, max_voxels, P, Fdim))
+        coors = points[0].new_zeros((B, max_voxels, 3), dtype=torch.int)
+        num = points[0].new_zeros((B, max_voxels), dtype=torch.int)
+        counts = torch.empty(B, dtype=torch.int32, device=dev)
+        for k, res in enumerate(points):
+            voxel_layer.hard_voxelize_async(res.contiguous(), voxels[k], coors[k], num[k], layer.voxel_size, layer.point_cloud_range,
+                                            P, max_voxels, counts[k:k + 1])
+        feats = torch.empty((cap, Fdim), dtype=torch.float32, device=dev)
+        coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        n_total = torch.empty(2, dtype=torch.int32, device=dev)
+        _lib.call("bfhip_voxel_compact_mean", voxels.data_ptr(), coors.data_ptr(), num.data_ptr(), counts.data_ptr(), B, max_voxels,
+                  P, Fdim, cap, feats.data_ptr(), coords.data_ptr(), n_total.data_ptr(), _lib.stream_of(feats))
+        self._voxel_monitor.submit(n_total)
+        return feats, coords, n_total[0:1]
+
+    def _static_lidar_ready(self):
+        layer, enc = self.pts_voxel_layer, self.pts_middle_encoder
+        hard = layer.max_num_points != -1 and (layer.max_voxels[0] if self.training else layer.max_voxels[1]) != -1
+        return (self.static_lidar and hard and self.voxelize_reduce and self.training and self._voxel_cap is not None
+                and getattr(enc, "static_caps", None) is not None)
+
     def extract_pts_feat(self, batch_inputs_dict) -> torch.Tensor:
         points = batch_inputs_dict["points"]
+        if points[0].is_cuda and self._static_lidar_ready():
+            with torch.autocast("cuda", enabled=False):
+                feats, coords, n_valid = self.voxelize_static([p.float() for p in points])
+            return self.pts_middle_encoder(feats, coords, len(points), n_valid=n_valid)
         with torch.autocast("cuda", enabled=False):  # fp32 island = voxelization only, as the reference (:201-206)
             points = [p.float() for p in points]
             feats, coords, sizes = self.voxelize(points)

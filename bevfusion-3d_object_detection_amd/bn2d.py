@@ -19,11 +19,12 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 _WS = {}
 
 
-def _apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial=None):
+def _apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial=None, rows_dev=None):
+    """rows_dev (optional int32[1] device tensor): number of ACTIVE rows of a capacity-sized matrix (the rest are zeros)."""
     ext = _lib.torch_ext()
-    if ext is not None and partial is None:  # C++ autograd front-end: same kernels, ~3x less host time per call
+    if ext is not None and partial is None and rows_dev is None:  # C++ autograd front-end: ~3x less host time per call
         return ext.bn2d(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu)
-    return _BN2dFunction.apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial)
+    return _BN2dFunction.apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial, rows_dev)
 
 
 _SIZES = {}
@@ -51,7 +52,7 @@ class _BN2dFunction(torch.autograd.Function):
     """y = act(BN_train(x) [+ residual]); x, residual, y channels-last [N, C, H, W], f32 or bf16."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial=None):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial=None, rows_dev=None):
         N, C, H, W = x.shape
         M, dt = N * H * W, _DT[x.dtype]
         res = None
@@ -65,13 +66,14 @@ class _BN2dFunction(torch.autograd.Function):
             # the producing convolution accumulated the column sums in its epilogue (conv2d.py): no statistics pass
             _lib.call("bfhip_bn2d_fwd_partials", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps,
                       momentum, 1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(),
-                      y.data_ptr(), partial.data_ptr(), partial.shape[0], stream)
+                      y.data_ptr(), partial.data_ptr(), partial.shape[0], _lib.ptr(rows_dev), stream)
         else:
             ws = _workspace(x.device, _ws_bytes(M, C, dt), stream)
             _lib.call("bfhip_bn2d_fwd", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps, momentum,
                       1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(), y.data_ptr(),
-                      ws.data_ptr(), ws.numel(), stream)
+                      _lib.ptr(rows_dev), ws.data_ptr(), ws.numel(), stream)
         keep_y = relu and residual is not None  # otherwise the ReLU mask is recomputed from x in the backward
+        ctx.rows_dev = rows_dev
         ctx.save_for_backward(x, y if keep_y else None, stats, weight)
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.res_dtype = residual.dtype if residual is not None else None
@@ -91,10 +93,11 @@ class _BN2dFunction(torch.autograd.Function):
         stream = _lib.stream_of(x)
         ws = _workspace(x.device, _ws_bytes(M, C, dt), stream)
         _lib.call("bfhip_bn2d_bwd", dy.data_ptr(), x.data_ptr(), _lib.ptr(y), stats.data_ptr(), weight.data_ptr(), M, C, dt,
-                  1 if ctx.relu else 0, dx.data_ptr(), _lib.ptr(dres), dgb.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                  1 if ctx.relu else 0, dx.data_ptr(), _lib.ptr(dres), dgb.data_ptr(), _lib.ptr(ctx.rows_dev), ws.data_ptr(),
+                  ws.numel(), stream)
         if dres is not None and ctx.res_dtype != dres.dtype:
             dres = dres.to(ctx.res_dtype)
-        return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None, None
+        return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None, None, None
 
 
 class _LazyBatchCounter:

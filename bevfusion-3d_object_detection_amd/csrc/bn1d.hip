@@ -65,8 +65,10 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
 }
 
 // stats[0][c] = mean, stats[1][c] = invstd; running stats updated like torch (unbiased var in running_var)
+// n_dev (optional): the number of ACTIVE rows lives on the device; rows beyond it are exact zeros (spconv.py, static
+// capacity mode), so only the divisor changes
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N,
-                                                          int C, float eps, float momentum,
+                                                          const int *__restrict__ n_dev, int C, float eps, float momentum,
                                                           float *__restrict__ stats,
                                                           float *__restrict__ running_mean,
                                                           float *__restrict__ running_var) {
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
   double s, s2;
   reduce_partials(partial, nblk, C, c, s, s2);
   if (threadIdx.x != 0) return;
+  if (n_dev) { int nv = *n_dev; N = nv < 1 ? 1 : (nv < N ? nv : N); }
   double mean = s / N;
   double var = s2 / N - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -155,10 +158,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restr
                                                            const float *__restrict__ stats,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ dgb, long long total4, int C,
-                                                           int N, int relu, float4 *__restrict__ dx,
-                                                           float4 *__restrict__ dres) {
+                                                           int N, const int *__restrict__ n_dev, int relu,
+                                                           float4 *__restrict__ dx, float4 *__restrict__ dres) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total4) return;
+  if (n_dev) { int nv = *n_dev; N = nv < 1 ? 1 : (nv < N ? nv : N); }
   const int c = (int)((t * 4) % C);
   float4 gv = dy[t], yv = y[t], xv = x[t];
   float g[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -192,7 +196,7 @@ BFHIP_EXPORT size_t bfhip_bn1d_workspace_bytes(int N, int C) {
 // Training-mode forward.  stats f32[2*C] receives (mean, invstd) for the backward; running_mean/var may be NULL.
 BFHIP_EXPORT int bfhip_bn1d_fwd(const float *x, const float *residual, const float *gamma, const float *beta, int N,
                                 int C, float eps, float momentum, int relu, float *running_mean,
-                                float *running_var, float *stats, float *y, void *workspace,
+                                float *running_var, float *stats, float *y, const int32_t *n_rows_dev, void *workspace,
                                 size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(shape_ok(N, C), "bn1d_fwd: needs N > 0 and C in {4,8,16,32,64,128,256} (N=%d C=%d)", N, C);
@@ -203,7 +207,7 @@ BFHIP_EXPORT int bfhip_bn1d_fwd(const float *x, const float *residual, const flo
   float *partial = (float *)workspace;
   int nblk = ceil_div(N, kSlab);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, stream, x, N, C, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, nblk, N, C, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, nblk, N, n_rows_dev, C, eps, momentum,
                      stats, running_mean, running_var);
   long long total4 = (long long)N * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, stream, (const float4 *)x,
@@ -214,7 +218,7 @@ BFHIP_EXPORT int bfhip_bn1d_fwd(const float *x, const float *residual, const flo
 // Backward.  dgb f32[2*C] receives (dgamma, dbeta); dres (optional) the gradient of the residual input.
 BFHIP_EXPORT int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x, const float *stats,
                                 const float *gamma, int N, int C, int relu, float *dx, float *dres, float *dgb,
-                                void *workspace, size_t workspace_bytes, void *stream_) {
+                                const int32_t *n_rows_dev, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(shape_ok(N, C), "bn1d_bwd: needs N > 0 and C in {4,8,16,32,64,128,256} (N=%d C=%d)", N, C);
   BFHIP_REQUIRE(dy && y && x && stats && gamma && dx && dgb, "bn1d_bwd: null pointer");
@@ -225,7 +229,7 @@ BFHIP_EXPORT int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x,
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, partial, nblk, C, dgb);
   long long total4 = (long long)N * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, stream, (const float4 *)dy,
-                     (const float4 *)y, (const float4 *)x, stats, gamma, dgb, total4, C, N, relu, (float4 *)dx,
+                     (const float4 *)y, (const float4 *)x, stats, gamma, dgb, total4, C, N, n_rows_dev, relu, (float4 *)dx,
                      (float4 *)dres);
   return check_launch("bn1d_bwd");
 }

@@ -145,8 +145,10 @@ __device__ __forceinline__ void reduce_partials8(const float *__restrict__ parti
 }
 
 // stats[0..C) mean, [C..2C) invstd, [2C..3C) a = gamma*invstd, [3C..4C) b = beta - mean*a
+// m_dev (optional): number of ACTIVE rows, on the device; the rows beyond it are exact zeros (feature matrices of the sparse
+// encoder in static capacity mode), so only the divisor changes
 __global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float *__restrict__ partial, int nblk, long long M,
-                                                            int C, float eps, float momentum,
+                                                            const int *__restrict__ m_dev, int C, float eps, float momentum,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta,
                                                             float *__restrict__ stats,
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float *__restr
   double s, s2;
   reduce_partials8(partial, nblk, C, c, c < C, s, s2);
   if (threadIdx.x >= 8 || c >= C) return;
+  if (m_dev) { long long mv = *m_dev; M = mv < 1 ? 1 : (mv < M ? mv : M); }
   double mean = s / (double)M;
   double var = s2 / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -285,13 +288,14 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T *__restric
 
 // dgb[0..C) dgamma, [C..2C) dbeta; coef[0..C) c1, [C..2C) c2, [2C..3C) c3 with dx = c1*g + c2*x + c3
 __global__ __launch_bounds__(256) void bn2d_bwd_finalize_kernel(const float *__restrict__ partial, int nblk,
-                                                                long long M, int C,
+                                                                long long M, const int *__restrict__ m_dev, int C,
                                                                 const float *__restrict__ stats,
                                                                 float *__restrict__ dgb, float *__restrict__ coef) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s, s2;
   reduce_partials8(partial, nblk, C, c, c < C, s, s2);
   if (threadIdx.x >= 8 || c >= C) return;
+  if (m_dev) { long long mv = *m_dev; M = mv < 1 ? 1 : (mv < M ? mv : M); }
   const float mean = stats[c], invstd = stats[C + c], a = stats[2 * C + c];
   const float dbeta = (float)s, dgamma = (float)(s2 * (double)invstd);
   dgb[c] = dgamma;
@@ -400,11 +404,11 @@ int run_fwd(const void *x, const void *res, const float *stats, long long M, int
 
 template <typename T, int MASK>
 void run_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma, long long M, int C,
-             Map mp, dim3 grid, float *partial, float *coef, float *dgb, void *dx, void *dres, hipStream_t s) {
+             Map mp, dim3 grid, float *partial, float *coef, float *dgb, void *dx, void *dres, const int *m_dev, hipStream_t s) {
   const int nblk = (int)grid.x;
   hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<T, MASK>), grid, dim3(256), 0, s, (const T *)dy, (const T *)x,
                      (const T *)y, stats, M, C, mp, partial);
-  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, C, stats, dgb,
+  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, m_dev, C, stats, dgb,
                      coef);
   if (dres)
     hipLaunchKernelGGL((bn2d_bwd_apply_kernel<T, MASK, true>), grid, dim3(256), 0, s, (const T *)dy, (const T *)x,
@@ -432,8 +436,8 @@ BFHIP_EXPORT size_t bfhip_bn2d_workspace_bytes(long long M, int C, int dtype) {
 
 BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float *gamma, const float *beta,
                                 long long M, int C, int dtype, float eps, float momentum, int relu,
-                                float *running_mean, float *running_var, float *stats, void *y, void *workspace,
-                                size_t workspace_bytes, void *stream_) {
+                                float *running_mean, float *running_var, float *stats, void *y, const int32_t *m_dev,
+                                void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   BFHIP_REQUIRE(bfhip_bn2d_supported(M, C, dtype), "bn2d_fwd: unsupported shape M=%lld C=%d dtype=%d", M, C, dtype);
   BFHIP_REQUIRE(x && gamma && beta && stats && y, "bn2d_fwd: null pointer");
@@ -448,7 +452,7 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
     hipLaunchKernelGGL(bn2d_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)x, M, C, mp, partial);
   else
     hipLaunchKernelGGL(bn2d_stats_kernel<float>, grid, dim3(256), 0, s, (const float *)x, M, C, mp, partial);
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, C, eps, momentum,
+  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, m_dev, C, eps, momentum,
                      gamma, beta, stats, running_mean, running_var);
   if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
   else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
@@ -458,7 +462,7 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
 BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta,
                                          long long M, int C, int dtype, float eps, float momentum, int relu,
                                          float *running_mean, float *running_var, float *stats, void *y,
-                                         const float *partial, int nblk, void *stream_) {
+                                         const float *partial, int nblk, const int32_t *m_dev, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   BFHIP_REQUIRE(bfhip_bn2d_supported(M, C, dtype), "bn2d_fwd_partials: unsupported shape M=%lld C=%d dtype=%d", M, C, dtype);
   BFHIP_REQUIRE(x && gamma && beta && stats && y && partial && nblk > 0, "bn2d_fwd_partials: null pointer");
@@ -466,7 +470,7 @@ BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, co
                 "bn2d_fwd_partials: tensors must be 16-byte aligned");
   dim3 grid;
   Map mp = make_map(M, C, dtype, &grid);
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, C, eps, momentum,
+  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, m_dev, C, eps, momentum,
                      gamma, beta, stats, running_mean, running_var);
   if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
   else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
@@ -475,7 +479,7 @@ BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, co
 
 BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma,
                                 long long M, int C, int dtype, int relu, void *dx, void *dres, float *dgb,
-                                void *workspace, size_t workspace_bytes, void *stream_) {
+                                const int32_t *m_dev, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   BFHIP_REQUIRE(bfhip_bn2d_supported(M, C, dtype), "bn2d_bwd: unsupported shape M=%lld C=%d dtype=%d", M, C, dtype);
   BFHIP_REQUIRE(dy && x && stats && gamma && dx && dgb, "bn2d_bwd: null pointer");
@@ -490,13 +494,13 @@ BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, co
   // ReLU mask: from the saved output when one is given (residual layers), otherwise recomputed from x
   const int mask = !relu ? 0 : (y ? 2 : 1);
   if (dtype == 1) {
-    if (mask == 0) run_bwd<bf16_t, 0>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, s);
-    else if (mask == 1) run_bwd<bf16_t, 1>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, s);
-    else run_bwd<bf16_t, 2>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, s);
+    if (mask == 0) run_bwd<bf16_t, 0>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
+    else if (mask == 1) run_bwd<bf16_t, 1>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
+    else run_bwd<bf16_t, 2>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
   } else {
-    if (mask == 0) run_bwd<float, 0>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, s);
-    else if (mask == 1) run_bwd<float, 1>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, s);
-    else run_bwd<float, 2>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, s);
+    if (mask == 0) run_bwd<float, 0>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
+    else if (mask == 1) run_bwd<float, 1>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
+    else run_bwd<float, 2>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
   }
   return check_launch("bn2d_bwd");
 }

@@ -314,6 +314,38 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
   for (int p = 0; p < P; ++p) s += voxels[((size_t)v * P + p) * F + f];
   out[t] = s / (float)num[v];
 }
+
+// BEVFusion.voxelize (BF/bevfusion.py:227-255) without its per-sample host reads: the B samples' hard-voxelization outputs
+// (each MV rows, true counts on the device) -> ONE capacity-sized [cap, F] matrix of per-voxel means and [cap, 4] coordinates
+// (b, x, y, z) whose ACTIVE rows are the prefix [0, min(sum of counts, cap)), in sample order like the reference's torch.cat;
+// the remaining rows are zeros with batch index -1 (inactive).  n_total[0] = active rows, n_total[1] = sum of counts.
+__global__ __launch_bounds__(256) void voxel_compact_mean_kernel(const float *__restrict__ voxels, const int *__restrict__ coors,
+                                                                 const int *__restrict__ num, const int *__restrict__ counts,
+                                                                 int B, int MV, int P, int F, int cap,
+                                                                 float *__restrict__ feats, int4 *__restrict__ out_coords,
+                                                                 int *__restrict__ n_total) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)cap * F) return;
+  const int r = (int)(t / F), f = (int)(t - (long long)r * F);
+  int off = 0, b = -1, local = 0;
+  for (int k = 0; k < B; ++k) {
+    int c = counts[k];
+    c = c < 0 ? 0 : (c > MV ? MV : c);
+    if (b < 0 && r < off + c) { b = k; local = r - off; }
+    off += c;
+  }
+  if (t == 0) { n_total[0] = off < cap ? off : cap; n_total[1] = off; }
+  if (b < 0) {
+    feats[t] = 0.f;
+    if (f == 0) out_coords[r] = make_int4(-1, -1, -1, -1);
+    return;
+  }
+  const size_t v = (size_t)b * MV + local;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += voxels[(v * P + p) * F + f];
+  feats[t] = s / (float)num[v];
+  if (f == 0) out_coords[r] = make_int4(b, coors[v * 3 + 0], coors[v * 3 + 1], coors[v * 3 + 2]);
+}
 } }
 
 BFHIP_EXPORT int bfhip_voxel_mean(const float *voxels, const int32_t *num_points, int M, int P, int F, float *out,
@@ -325,4 +357,16 @@ BFHIP_EXPORT int bfhip_voxel_mean(const float *voxels, const int32_t *num_points
   long long total = (long long)M * F;
   hipLaunchKernelGGL(voxel_mean_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, voxels, num_points, total, P, F, out);
   return check_launch("voxel_mean");
+}
+
+BFHIP_EXPORT int bfhip_voxel_compact_mean(const float *voxels, const int32_t *coors, const int32_t *num_points,
+                                          const int32_t *counts_dev, int B, int max_voxels, int P, int F, int cap,
+                                          float *feats, int32_t *out_coords, int32_t *n_total_dev, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BFHIP_REQUIRE(B > 0 && B <= 64 && max_voxels > 0 && P > 0 && F > 0 && cap > 0, "voxel_compact_mean: bad sizes");
+  BFHIP_REQUIRE(voxels && coors && num_points && counts_dev && feats && out_coords && n_total_dev, "voxel_compact_mean: null pointer");
+  BFHIP_REQUIRE(((uintptr_t)out_coords % 16) == 0, "voxel_compact_mean: out_coords must be 16-byte aligned");
+  hipLaunchKernelGGL(voxel_compact_mean_kernel, dim3(ceil_div((long long)cap * F, 256)), dim3(256), 0, stream, voxels, coors,
+                     num_points, counts_dev, B, max_voxels, P, F, cap, feats, (int4 *)out_coords, n_total_dev);
+  return check_launch("voxel_compact_mean");
 }

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void subm_insert_kernel(const int4 *__restrict
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   int4 c = indices[n];
+  if (c.x < 0) return;  // inactive row of a capacity-sized tensor (spconv.py, static capacity mode)
   int key = ((c.x * G.in0 + c.y) * G.in1 + c.z) * G.in2 + c.w;
   unsigned s = hash32((unsigned)key) & mask;
   for (unsigned probe = 0; probe <= mask; ++probe) {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void subm_pairs_kernel(const int4 *__restrict_
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
   int found = -1;
-  if (n < N) {
+  if (n < N && indices[n].x >= 0) {
     int4 c = indices[n];
     int l = k % G.k2, j = (k / G.k2) % G.k1, i = k / (G.k2 * G.k1);
     int dx_ = (i - G.k0 / 2) * G.d0, dy_ = (j - G.k1 / 2) * G.d1, dz_ = (l - G.k2 / 2) * G.d2;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void sparse_mark_kernel(const int4 *__restrict
   if (n >= N || (n_dev && n >= *n_dev)) return;
   int ox, oy, oz;
   int4 c = indices[n];
-  if (!out_coord(G, c, k, ox, oy, oz)) return;
+  if (c.x < 0 || !out_coord(G, c, k, ox, oy, oz)) return;
   long long cell = (((long long)c.x * G.out0 + ox) * G.out1 + oy) * G.out2 + oz;
   atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));
 }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void sparse_pairs_kernel(const int4 *__restric
   if (n < N) {
     int ox, oy, oz;
     int4 c = indices[n];
-    ok = out_coord(G, c, k, ox, oy, oz);
+    ok = c.x >= 0 && out_coord(G, c, k, ox, oy, oz);
     int o = -1;
     if (ok) {
       long long cell = (((long long)c.x * G.out0 + ox) * G.out1 + oy) * G.out2 + oz;
@@ -1128,6 +1129,7 @@ __global__ __launch_bounds__(256) void sparse_to_bev_kernel(const float *__restr
   int c = (int)(t - n * C);
   if (n >= N) return;
   int4 id = indices[n];
+  if (id.x < 0) return;  // inactive row
   out[((((size_t)id.x * C + c) * Z + id.w) * X + id.y) * Y + id.z] = feats[t];
 }
 
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(256) void bev_to_sparse_kernel(const float *__restr
   int c = (int)(t - n * C);
   if (n >= N) return;
   int4 id = indices[n];
-  grad_feats[t] = grad_out[((((size_t)id.x * C + c) * Z + id.w) * X + id.y) * Y + id.z];
+  grad_feats[t] = id.x < 0 ? 0.f : grad_out[((((size_t)id.x * C + c) * Z + id.w) * X + id.y) * Y + id.z];
 }
 
 // channels-last variants: out[b][x][y][c*Z + z] (the NHWC memory of the [B, C*Z, X, Y] BEV map), f32 or bf16; a sparse row's
@@ -1160,6 +1162,7 @@ __global__ __launch_bounds__(256) void sparse_to_bev_nhwc_kernel(const float *__
   int c = (int)(t - n * C);
   if (n >= N) return;
   int4 id = indices[n];
+  if (id.x < 0) return;  // inactive row
   size_t o = (((size_t)id.x * X + id.y) * Y + id.z) * ((size_t)C * Z) + (size_t)c * Z + id.w;
   if (sizeof(T) == 2) ((unsigned short *)out)[o] = f32_to_bf16_rne(feats[t]);
   else ((float *)out)[o] = feats[t];
@@ -1175,6 +1178,7 @@ __global__ __launch_bounds__(256) void bev_nhwc_to_sparse_kernel(const T *__rest
   int c = (int)(t - n * C);
   if (n >= N) return;
   int4 id = indices[n];
+  if (id.x < 0) { grad_feats[t] = 0.f; return; }
   size_t o = (size_t)(id.x * sb + id.y * sx + id.z * sy) + (size_t)c * Z + id.w;
   if (sizeof(T) == 2) grad_feats[t] = __uint_as_float((unsigned)((const unsigned short *)grad)[o] << 16);
   else grad_feats[t] = ((const float *)grad)[o];
@@ -1583,6 +1587,8 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
   hipMemsetAsync(pair_fwd, 0xff, (size_t)G.KV * n_out * sizeof(int), stream);
+  // n_out may be a capacity (true count only on the device): rows the kernel below does not reach stay inactive (-1)
+  hipMemsetAsync(out_indices, 0xff, (size_t)n_out * sizeof(int4), stream);
   hipLaunchKernelGGL(sparse_out_indices_kernel, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream, bitmap, word_prefix,
                      nwords, G, n_out, (int4 *)out_indices);
   hipLaunchKernelGGL(sparse_pairs_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, G,

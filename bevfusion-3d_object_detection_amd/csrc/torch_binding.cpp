@@ -43,7 +43,7 @@ class BN2dFn : public torch::autograd::Function<BN2dFn> {
     check(bfhip_bn2d_fwd(x.data_ptr(), res.defined() ? res.data_ptr() : nullptr, weight.data_ptr<float>(),
                          bias.data_ptr<float>(), M, (int)C, dt, (float)eps, (float)momentum, relu ? 1 : 0,
                          running_mean.data_ptr<float>(), running_var.data_ptr<float>(), stats.data_ptr<float>(), y.data_ptr(),
-                         ws.data_ptr(), wsb, cur_stream(x)),
+                         nullptr, ws.data_ptr(), wsb, cur_stream(x)),
           "bn2d_fwd");
     const bool keep_y = relu && res.defined();  // otherwise the ReLU mask is recomputed from x
     ctx->save_for_backward({x, keep_y ? y : Tensor(), stats, weight});
@@ -69,7 +69,7 @@ class BN2dFn : public torch::autograd::Function<BN2dFn> {
     Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
     check(bfhip_bn2d_bwd(dy.data_ptr(), x.data_ptr(), y.defined() ? y.data_ptr() : nullptr, stats.data_ptr<float>(),
                          weight.data_ptr<float>(), M, (int)C, dt, relu ? 1 : 0, dx.data_ptr(),
-                         dres.defined() ? dres.data_ptr() : nullptr, dgb.data_ptr<float>(), ws.data_ptr(), wsb, cur_stream(x)),
+                         dres.defined() ? dres.data_ptr() : nullptr, dgb.data_ptr<float>(), nullptr, ws.data_ptr(), wsb, cur_stream(x)),
           "bn2d_bwd");
     if (has_res) {
       auto rdt = (at::ScalarType)ctx->saved_data["res_dtype"].toInt();
@@ -101,7 +101,7 @@ class BN1dFn : public torch::autograd::Function<BN1dFn> {
     check(bfhip_bn1d_fwd(x.data_ptr<float>(), res.defined() ? res.data_ptr<float>() : nullptr, weight.data_ptr<float>(),
                          bias.data_ptr<float>(), (int)N, (int)C, (float)eps, (float)momentum, relu ? 1 : 0,
                          running_mean.data_ptr<float>(), running_var.data_ptr<float>(), stats.data_ptr<float>(),
-                         y.data_ptr<float>(), ws.data_ptr(), wsb, cur_stream(x)),
+                         y.data_ptr<float>(), nullptr, ws.data_ptr(), wsb, cur_stream(x)),
           "bn1d_fwd");
     ctx->save_for_backward({x, y, stats, weight});
     ctx->saved_data["relu"] = relu;
@@ -122,7 +122,7 @@ class BN1dFn : public torch::autograd::Function<BN1dFn> {
     Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
     check(bfhip_bn1d_bwd(dy.data_ptr<float>(), y.data_ptr<float>(), x.data_ptr<float>(), stats.data_ptr<float>(),
                          weight.data_ptr<float>(), (int)N, (int)C, relu ? 1 : 0, dx.data_ptr<float>(),
-                         dres.defined() ? dres.data_ptr<float>() : nullptr, dgb.data_ptr<float>(), ws.data_ptr(), wsb,
+                         dres.defined() ? dres.data_ptr<float>() : nullptr, dgb.data_ptr<float>(), nullptr, ws.data_ptr(), wsb,
                          cur_stream(x)),
           "bn1d_bwd");
     return {dx, dres, dgb.slice(0, 0, C), dgb.slice(0, C, 2 * C), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};

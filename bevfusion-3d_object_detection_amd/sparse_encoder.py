@@ -10,8 +10,8 @@ import torch
 from torch import nn
 
 from .registry import MODELS
-from .spconv import (BatchNorm1dAct, SparseConv3d, SparseConvTensor, SparseModule, SparseSequential,  # noqa: F401
-                     SubMConv3d, prepare_strided_rulebooks, replace_feature)
+from .spconv import (BatchNorm1dAct, CapacityMonitor, SparseConv3d, SparseConvTensor, SparseModule,  # noqa: F401
+                     SparseSequential, SubMConv3d, prepare_strided_rulebooks, replace_feature, round_capacity)
 
 _CONV_TYPES = {"SubMConv3d": SubMConv3d, "SparseConv3d": SparseConv3d}
 
@@ -63,12 +63,12 @@ class SparseBasicBlock(SparseModule):
         identity = x.features
         assert x.features.dim() == 2
         out = self.conv1(x)
-        out = replace_feature(out, self.norm1(out.features, relu=True))
+        out = replace_feature(out, self.norm1(out.features, relu=True, rows_dev=out.n_valid))
         out = self.conv2(out)
         if self.downsample is not None:
             identity = self.downsample(x).features
         # norm2 + identity + ReLU in one pass
-        return replace_feature(out, self.norm2(out.features, residual=identity, relu=True))
+        return replace_feature(out, self.norm2(out.features, residual=identity, relu=True, rows_dev=out.n_valid))
 
 
 @MODELS.register_module()
@@ -102,6 +102,11 @@ class BEVFusionSparseEncoder(nn.Module):
         # count the outputs of all strided layers up front: one host read per forward (BFHIP_PRESIZE_RULEBOOKS=0: one per layer)
         self.presize_rulebooks = os.environ.get("BFHIP_PRESIZE_RULEBOOKS", "1") == "1"
         self._nout_hints = []  # N_out of the strided layers in the previous forward: sizes the capped buffers of the next one
+        # static capacity mode (forward(..., n_valid=...)): row capacities of the strided layers (grow-only) and the
+        # stall-free watcher of the true counts
+        self.static_caps = None
+        self._monitor = CapacityMonitor()
+        self.overflowed = False
         first_order = ("conv",) if order[0] != "conv" else order  # pre-activation variant keeps a bare first conv
         self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
                                                  indice_key="subm1", conv_type="SubMConv3d", order=first_order)
@@ -139,15 +144,45 @@ class BEVFusionSparseEncoder(nn.Module):
             self.encoder_layers.add_module(f"encoder_layer{i + 1}", SparseSequential(*blocks_list))
         return out_channels
 
-    def forward(self, voxel_features, coors, batch_size):
+    def update_static_caps(self, n_outs):
+        """Grow-only capacities from observed strided-layer output counts."""
+        caps = [round_capacity(n) for n in n_outs]
+        if self.static_caps is None or len(self.static_caps) != len(caps):
+            self.static_caps = caps
+        else:
+            self.static_caps = [max(a, b) for a, b in zip(self.static_caps, caps)]
+
+    def forward(self, voxel_features, coors, batch_size, n_valid=None):
+        """n_valid (device i32[1]): static capacity mode -- `voxel_features` / `coors` are capacity-sized with the active rows
+        as a prefix (BEVFusion.voxelize_static); every row count stays on the device and NO host read happens."""
         coors = coors.int()
         x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
-        if self.presize_rulebooks and coors.is_cuda:
+        if n_valid is not None:
+            assert self.static_caps is not None, "static capacity mode needs capacities (run one exact forward first)"
+            seen = self._monitor.poll()  # true counts of an EARLIER forward, if they have arrived: no stall
+            if seen is not None:
+                if any(n > c for n, c in zip(seen, self.static_caps)):
+                    self.overflowed = True  # that forward dropped rows beyond its capacity: grown below for the next ones
+                    import warnings
+                    warnings.warn("sparse encoder: a strided layer exceeded its row capacity %s < %s; capacities grown"
+                                  % (self.static_caps, seen))
+                self.update_static_caps(seen)
+            x.n_valid = n_valid
+            chain = [m for m in self.modules() if isinstance(m, SparseConv3d)]
+            plans, true_counts = prepare_strided_rulebooks(
+                coors, batch_size, self.sparse_shape, [(m.kernel_size, m.stride, m.padding, m.dilation) for m in chain],
+                static_caps=self.static_caps, n_in_dev=n_valid)
+            x.indice_dict["_strided_plans"] = plans
+            if true_counts is not None:
+                self._monitor.submit(true_counts)
+        elif self.presize_rulebooks and coors.is_cuda:
             # all strided layers' output counts in ONE host read (instead of one per layer)
             chain = [m for m in self.modules() if isinstance(m, SparseConv3d)]  # registration order = execution order
             x.indice_dict["_strided_plans"] = prepare_strided_rulebooks(
                 coors, batch_size, self.sparse_shape, [(m.kernel_size, m.stride, m.padding, m.dilation) for m in chain],
                 hints=self._nout_hints)
+            if len(self._nout_hints) == len(chain):
+                self.update_static_caps(self._nout_hints)
         x = self.conv_input(x)
         encode_features = []
         for encoder_layer in self.encoder_layers:

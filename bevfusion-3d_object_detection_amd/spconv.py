@@ -42,7 +42,8 @@ class IndiceData:
     """Rulebook of one convolution (what spconv keeps in `indice_dict[indice_key]`)."""
 
     def __init__(self, out_indices, pair_fwd, pair_bwd, n_pairs, is_subm, out_spatial_shape, ksize, stride, padding,
-                 dilation):
+                 dilation, n_out_dev=None):
+        self.n_out_dev = n_out_dev          # static capacity mode: true N_out (device i32[1]); out_indices has capacity rows
         self.out_indices = out_indices      # i32[N_out, 4]
         self.pair_fwd = pair_fwd            # i32[KV, N_out]
         self.pair_bwd = pair_bwd            # i32[KV, N_in] (None for SubM: pair_fwd with flipped offsets)
@@ -105,25 +106,30 @@ class StridedPlan:
 
     def __init__(self, geo_key, n_out, counts, ws):
         self.geo_key, self.n_out, self.counts, self.ws = geo_key, n_out, counts, ws
+        self.n_out_dev = None  # static capacity mode: n_out is a capacity, the true count is this device scalar
 
 
 def _geo_key(spatial_shape, ksize, stride, padding, dilation):
     return (tuple(spatial_shape), tuple(ksize), tuple(stride), tuple(padding), tuple(dilation))
 
 
-def prepare_strided_rulebooks(indices, batch_size, spatial_shape, specs, hints=None):
+def prepare_strided_rulebooks(indices, batch_size, spatial_shape, specs, hints=None, static_caps=None, n_in_dev=None):
     """Count the outputs of a CHAIN of strided sparse convs (specs: [(ksize, stride, padding, dilation), ...], each applied to
     the previous one's output coordinates; SubM layers in between do not change coordinates) with ONE host read for all of
     them instead of one per layer.  Output coordinates of a level go into a capped buffer whose true length
     stays on the device and feeds the next level's count.  Returns {geometry key: StridedPlan}; a level whose N_out
     exceeded its cap (and everything after it) is left out and takes the per-layer path.  `hints` (the N_out values of the
     previous forward, if any) tighten the caps to 1.5x: consecutive frames have similar occupancy, and the launches of the
-    following level are sized by the cap."""
+    following level are sized by the cap.
+
+    Static capacity mode (`static_caps`: one row capacity per level, `n_in_dev`: active input rows on the device): NO host
+    read at all -- every level's outputs live in a buffer of its capacity, the true counts stay on the device
+    (`plan.n_out_dev`) and rows beyond them are inactive (batch index -1).  Returns ({key: plan}, true-count tensor) then."""
     dev = indices.device
     lib = _lib.load()
     stream = _lib.stream_of(indices)
     N0 = indices.shape[0]
-    cur_idx, cur_cap, cur_n_dev, shape = indices, N0, None, list(spatial_shape)
+    cur_idx, cur_cap, cur_n_dev, shape = indices, N0, n_in_dev, list(spatial_shape)
     levels = []
     if N0 == 0:
         return {}
@@ -137,7 +143,9 @@ def prepare_strided_rulebooks(indices, batch_size, spatial_shape, specs, hints=N
             out_shape = conv_out_shape(shape, ksize, stride, padding, dilation)
             cells = batch_size * out_shape[0] * out_shape[1] * out_shape[2]
             cap = int(min(cells, 8 * cur_cap, max(4 * N0, 1 << 16)))
-            if hints is not None and len(levels) < len(hints) and hints[len(levels)] > 0:
+            if static_caps is not None:
+                cap = int(min(cells, static_caps[len(levels)]))
+            elif hints is not None and len(levels) < len(hints) and hints[len(levels)] > 0:
                 cap = int(min(cap, hints[len(levels)] * 3 // 2 + 4096))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)  # kept until the layer's fill
             counts = torch.zeros(65, dtype=torch.int32, device=dev)
@@ -148,6 +156,13 @@ def prepare_strided_rulebooks(indices, batch_size, spatial_shape, specs, hints=N
                                                              stream), "rulebook_sparse_out_indices")
             levels.append((_geo_key(shape, ksize, stride, padding, dilation), counts, ws, cap))
             cur_idx, cur_cap, cur_n_dev, shape = tmp_idx, cap, counts[0:1], out_shape
+    if static_caps is not None:
+        plans = {}
+        for key, counts, ws, cap in levels:
+            plan = StridedPlan(key, cap, counts, ws)
+            plan.n_out_dev = counts[0:1]
+            plans[key] = plan
+        return plans, torch.stack([c[0] for _, c, _, _ in levels]) if levels else None
     if not levels:
         return {}
     n_outs = torch.stack([c[0] for _, c, _, _ in levels]).tolist()  # the one host read
@@ -159,6 +174,39 @@ def prepare_strided_rulebooks(indices, batch_size, spatial_shape, specs, hints=N
             break  # this level (and its successors, counted from a truncated input) falls back to the per-layer path
         plans[key] = StridedPlan(key, int(n_out), counts, ws)
     return plans
+
+
+class CapacityMonitor:
+    """Static capacity mode keeps every row count on the device; this watches them WITHOUT a host stall: the true counts of
+    a forward are copied to pinned memory behind the forward's kernels, and read at the start of a later forward once
+    their event has completed (event.query() is not a synchronising call)."""
+
+    def __init__(self):
+        self.pinned = self.event = None
+        self.pending = False
+
+    def submit(self, counts_dev):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        n = counts_dev.numel()
+        if self.pinned is None or self.pinned.numel() != n:
+            self.pinned = torch.empty(n, dtype=torch.int32).pin_memory()
+            self.event = torch.cuda.Event()
+        self.pinned.copy_(counts_dev, non_blocking=True)
+        self.event.record()
+        self.pending = True
+
+    def poll(self):
+        """The counts of the last submitted forward if they have arrived, else None."""
+        if self.pending and self.event.query():
+            self.pending = False
+            return self.pinned.tolist()
+        return None
+
+
+def round_capacity(n):
+    """Row capacity for an observed count n: 1.5x + 4096, rounded up to 4096 (grow-only at the call sites)."""
+    return (int(n) * 3 // 2 + 4096 + 4095) // 4096 * 4096
 
 
 def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, plan=None):
@@ -190,7 +238,8 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
                                             ws.numel(), stream)
     _lib.check(rc, "rulebook_sparse_fill")
     return IndiceData(out_indices, pair_fwd, pair_bwd, counts[1:], False,
-                      conv_out_shape(spatial_shape, ksize, stride, padding, dilation), ksize, stride, padding, dilation)
+                      conv_out_shape(spatial_shape, ksize, stride, padding, dilation), ksize, stride, padding, dilation,
+                      n_out_dev=plan.n_out_dev if plan is not None else None)
 
 
 def _bf16_ok(weight, transpose):
@@ -367,6 +416,9 @@ class SparseConvTensor:
         self.indice_dict = indice_dict if indice_dict is not None else {}
         self.benchmark = benchmark
         self._auto_rulebooks = {}  # SubM rulebooks keyed by (ksize, dilation); valid while indices are unchanged
+        # static capacity mode: device i32[1] number of ACTIVE rows (a prefix); the other rows have batch index -1 and zero
+        # features and are skipped by every index-driven kernel.  None: every row is active (exact sizes).
+        self.n_valid = None
 
     def replace_feature(self, feature):
         new = self.shadow_copy()
@@ -377,6 +429,7 @@ class SparseConvTensor:
         t = SparseConvTensor(self.features, self.indices, self.spatial_shape, self.batch_size,
                              indice_dict=self.indice_dict, benchmark=self.benchmark)
         t._auto_rulebooks = self._auto_rulebooks
+        t.n_valid = self.n_valid
         return t
 
     def find_indice_pair(self, key):
@@ -414,9 +467,10 @@ class _BN1dFunction(torch.autograd.Function):
     """y = act(BN_train(x) [+ residual]) on f32[N, C] (csrc/bn1d.hip)."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, rows_dev=None):
         x = x.contiguous()
         N, C = x.shape
+        ctx.rows_dev = rows_dev
         res = residual.contiguous() if residual is not None else None
         y = torch.empty_like(x)
         stats = torch.empty(2 * C, dtype=torch.float32, device=x.device)
@@ -425,7 +479,8 @@ class _BN1dFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = lib.bfhip_bn1d_fwd(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), N, C, float(eps),
                                     float(momentum), 1 if relu else 0, _lib.ptr(running_mean), _lib.ptr(running_var),
-                                    _lib.ptr(stats), _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
+                                    _lib.ptr(stats), _lib.ptr(y), _lib.ptr(rows_dev), _lib.ptr(ws), ws.numel(),
+                                    _lib.stream_of(x))
         _lib.check(rc, "bn1d_fwd")
         ctx.save_for_backward(x, y, stats, weight)
         ctx.relu = relu
@@ -444,17 +499,18 @@ class _BN1dFunction(torch.autograd.Function):
         ws = _workspace(x.device, lib.bfhip_bn1d_workspace_bytes(N, C), "bn1d")
         with torch.cuda.device(x.device):
             rc = lib.bfhip_bn1d_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(weight), N, C,
-                                    1 if ctx.relu else 0, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgb), _lib.ptr(ws),
-                                    ws.numel(), _lib.stream_of(x))
+                                    1 if ctx.relu else 0, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgb), _lib.ptr(ctx.rows_dev),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
         _lib.check(rc, "bn1d_bwd")
-        return dx, dres, dgb[:C], dgb[C:], None, None, None, None, None
+        return dx, dres, dgb[:C], dgb[C:], None, None, None, None, None, None
 
 
 class BatchNorm1dAct(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters / buffers / state_dict keys) whose forward can also add a residual and apply
     ReLU; in training mode on fp32 CUDA features of a supported width it runs the fused HIP kernels."""
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, rows_dev=None):
+        """rows_dev (static capacity mode): device i32[1] count of ACTIVE rows; the rows beyond it are zeros on entry."""
         C = x.shape[1] if x.dim() == 2 else 0
         if (FUSED_BN1D and self.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and x.shape[0] > 1
                 and self.affine and self.track_running_stats and self.momentum is not None and C % 8 == 0):
@@ -465,7 +521,7 @@ class BatchNorm1dAct(nn.BatchNorm1d):
             N = x.shape[0]
             res = residual.contiguous().view(N, C, 1, 1) if residual is not None else None
             y = bn2d._apply(x.contiguous().view(N, C, 1, 1), res, self.weight, self.bias, self.running_mean, self.running_var,
-                            self.eps, self.momentum, relu)
+                            self.eps, self.momentum, relu, rows_dev=rows_dev)
             return y.view(N, C)
         fused = (FUSED_BN1D and self.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 1
                  and self.affine and self.track_running_stats and self.momentum is not None
@@ -474,11 +530,13 @@ class BatchNorm1dAct(nn.BatchNorm1d):
             if self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)
             ext = _lib.torch_ext()
-            if ext is not None:
+            if ext is not None and rows_dev is None:
                 return ext.bn1d(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                 self.momentum, relu)
             return _BN1dFunction.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                                       self.momentum, relu)
+                                       self.momentum, relu, rows_dev)
+        if rows_dev is not None:
+            raise RuntimeError("capacity-sized feature matrices need the fused BatchNorm kernels (training mode, supported width)")
         out = super().forward(x)
         if residual is not None:
             out = out + residual
@@ -546,8 +604,10 @@ class SparseSequential(SparseModule):
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     if isinstance(module, BatchNorm1dAct) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
-                        input = input.replace_feature(module(input.features, relu=True))  # BN + ReLU in one pass
+                        input = input.replace_feature(module(input.features, relu=True, rows_dev=input.n_valid))  # BN + ReLU
                         i += 1
+                    elif isinstance(module, BatchNorm1dAct):
+                        input = input.replace_feature(module(input.features, rows_dev=input.n_valid))
                     else:
                         input = input.replace_feature(module(input.features))
             else:
@@ -615,6 +675,8 @@ class SparseConvolution(SparseModule):
         assert isinstance(input, SparseConvTensor)
         assert input.features.shape[1] == self.in_channels, "channel size mismatch"
         _lib.require_cuda(input.features, "features")
+        if input.n_valid is not None and self.bias is not None:
+            raise RuntimeError("static capacity mode needs bias-free sparse convolutions (inactive rows must stay zero)")
         data = self._rulebook(input)
         n_in = input.features.shape[0]
         out_features = _SparseConvFunction.apply(input.features, self.weight, data, n_in)
@@ -624,6 +686,7 @@ class SparseConvolution(SparseModule):
             return input.replace_feature(out_features)
         out = SparseConvTensor(out_features, data.out_indices, data.out_spatial_shape, input.batch_size,
                                indice_dict=input.indice_dict, benchmark=input.benchmark)
+        out.n_valid = data.n_out_dev
         return out
 
 

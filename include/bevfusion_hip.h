@@ -292,12 +292,14 @@ int bfhip_depth_histogram(const float *depth, int BN, int iH, int iW, int fH, in
  *   C must divide 256 and be a multiple of 4; tensors 16-byte aligned.
  * --------------------------------------------------------------------------------------- */
 size_t bfhip_bn1d_workspace_bytes(int N, int C);
+/* n_rows_dev / m_dev (optional, both BatchNorm families): the number of ACTIVE rows when N / M is only a capacity (feature
+ * matrices of the sparse encoder sized by bounds, true counts on the device: no host read); the rows beyond it must be zero. */
 int bfhip_bn1d_fwd(const float *x, const float *residual, const float *gamma, const float *beta, int N, int C,
                    float eps, float momentum, int relu, float *running_mean, float *running_var, float *stats,
-                   float *y, void *workspace, size_t workspace_bytes, void *stream);
+                   float *y, const int32_t *n_rows_dev, void *workspace, size_t workspace_bytes, void *stream);
 int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x, const float *stats, const float *gamma, int N,
-                   int C, int relu, float *dx, float *dres, float *dgb, void *workspace, size_t workspace_bytes,
-                   void *stream);
+                   int C, int relu, float *dx, float *dres, float *dgb, const int32_t *n_rows_dev, void *workspace,
+                   size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d (+ residual) (+ ReLU), training mode, on channels-last activations viewed as [M = N*H*W, C]
@@ -313,9 +315,9 @@ int bfhip_bn2d_supported(long long M, int C, int dtype);
 size_t bfhip_bn2d_workspace_bytes(long long M, int C, int dtype);
 int bfhip_bn2d_fwd(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
                    int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
-                   float *stats, void *y, void *workspace, size_t workspace_bytes, void *stream);
+                   float *stats, void *y, const int32_t *m_dev, void *workspace, size_t workspace_bytes, void *stream);
 int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma, long long M,
-                   int C, int dtype, int relu, void *dx, void *dres, float *dgb, void *workspace,
+                   int C, int dtype, int relu, void *dx, void *dres, float *dgb, const int32_t *m_dev, void *workspace,
                    size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -419,6 +421,15 @@ int bfhip_query_losses(const float *cls_logits, const int32_t *labels, const flo
                        const float *code_weights, int B, int C, int P, int K, int ld, int p_off, float gamma,
                        float alpha, float *grad_cls, float *grad_box, float *loss_sums, void *stream);
 
+/* BEVFusion.voxelize (projects/BEVFusion/bevfusion/bevfusion.py:227-255: per-sample voxelize, F.pad batch id, cat, mean) for B
+ * samples without the per-sample host reads: voxels f32[B][max_voxels][P][F], coors i32[B][max_voxels][3], num_points
+ * i32[B][max_voxels], counts_dev i32[B] (what bfhip_hard_voxelize left on the device) -> feats f32[cap][F] (per-voxel means),
+ * out_coords i32[cap][4] = (b, x, y, z); active rows are the prefix, the rest are zeros with b = -1 (inactive rows: every
+ * index-driven kernel of this library skips them); n_total_dev i32[2] = (active rows, sum of counts). */
+int bfhip_voxel_compact_mean(const float *voxels, const int32_t *coors, const int32_t *num_points, const int32_t *counts_dev,
+                             int B, int max_voxels, int P, int F, int cap, float *feats, int32_t *out_coords,
+                             int32_t *n_total_dev, void *stream);
+
 /* ---- dense 2-D convolution, channels-last bf16, implicit GEMM on the matrix cores (csrc/conv2d.hip).
  * Replaces the cuDNN convolutions behind torch.nn.Conv2d of ConvFuser (projects/BEVFusion/bevfusion/bevfusion_head.py:26-38),
  * SECOND / SECONDFPN (mmdet3d/models/backbones/second.py:27-95, necks/second_fpn.py:30-94), shared_conv (:95-102),
@@ -443,7 +454,7 @@ int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw
  * f32[nblk][2][C] (column sums, sums of squares per row block).  Otherwise as bfhip_bn2d_fwd. */
 int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
                             int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
-                            float *stats, void *y, const float *partial, int nblk, void *stream);
+                            float *stats, void *y, const float *partial, int nblk, const int32_t *m_dev, void *stream);
 
 #ifdef __cplusplus
 }
