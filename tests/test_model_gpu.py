@@ -74,6 +74,8 @@ def test_side_stream_matches_single_stream(dev):
     hook = model.pts_middle_encoder.register_forward_hook(lambda m, i, o: captured.__setitem__("pts", o))
     weight = torch.randn(1, 256, 180, 180, device=dev)
     results = []
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        model.extract_feat(inp)  # learns the LiDAR branch's row capacities: both runs below take the static (sync-free) path
     for side in (False, True):
         model.lidar_side_stream = side
         model.zero_grad(set_to_none=True)
