@@ -77,10 +77,10 @@ SIGNATURES = {
     "bfhip_xty": (_c_int, [_c_vp, _c_vp, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_attn_workspace_bytes": (_c_sz, [_c_int] * 4),
     "bfhip_attn_fwd": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _c_vp, _c_vp,
-                                                             _c_vp, _c_sz, _c_vp]),
-    "bfhip_attn_bwd": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong] + [_c_vp] * 3 +
+                                                             _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_attn_bwd": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong] + [_c_vp] * 4 +
                        [_c_vp, _c_sz, _c_vp]),
-    "bfhip_attn_dropout_mask": (_c_int, [_c_int] * 4 + [ctypes.c_float, ctypes.c_ulonglong, _c_vp, _c_vp]),
+    "bfhip_attn_dropout_mask": (_c_int, [_c_int] * 4 + [ctypes.c_float, ctypes.c_ulonglong, _c_vp, _c_vp, _c_vp]),
     "bfhip_upsample2x_nhwc": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp]),
     "bfhip_circle_nms": (_c_int, [_c_vp, _c_int, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp]),
     "bfhip_rotate_nms_workspace_bytes": (_c_sz, [_c_int, _c_int]),

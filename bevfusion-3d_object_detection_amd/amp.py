@@ -29,7 +29,8 @@ def low_precision_parameters(model, exclude=("pts_middle_encoder", "heatmap_head
 class MasterWeightAdamW:
     """AdamW (fused) over fp32 master copies of `low` (converted to bf16 in place) plus the remaining fp32 parameters."""
 
-    def __init__(self, model, lr, weight_decay, max_grad_norm=None, exclude=("pts_middle_encoder", "heatmap_head")):
+    def __init__(self, model, lr, weight_decay, max_grad_norm=None, exclude=("pts_middle_encoder", "heatmap_head"),
+                 capturable=False):
         self.low = low_precision_parameters(model, exclude)
         low_ids = {id(p) for p in self.low}
         self.other = [p for p in model.parameters() if p.requires_grad and id(p) not in low_ids]
@@ -39,7 +40,9 @@ class MasterWeightAdamW:
         for m in self.master:
             m.grad = torch.zeros_like(m)
         self.max_grad_norm = max_grad_norm
-        self.opt = torch.optim.AdamW(self.master + self.other, lr=lr, weight_decay=weight_decay, fused=True)
+        # capturable: step counters live on the device, so step() can sit inside a captured hipGraph
+        self.opt = torch.optim.AdamW(self.master + self.other, lr=lr, weight_decay=weight_decay, fused=True,
+                                     capturable=capturable)
 
     def zero_grad(self):
         for p in self.low:

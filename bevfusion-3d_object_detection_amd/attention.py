@@ -35,10 +35,25 @@ def next_seed():
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_calls) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
+_step_counter = {}
+
+
+def step_counter(device):
+    """Device-side u64 call counter mixed into every dropout seed (csrc/attn.hip eff_seed).  Advance it INSIDE a captured
+    training step (`step_counter(dev).add_(1)`): a replayed hipGraph repeats its host-side seed argument, the counter still
+    gives every replay its own mask.  Zero (the default) leaves the host seed as it is."""
+    key = torch.device(device)
+    t = _step_counter.get(key)
+    if t is None:
+        t = _step_counter[key] = torch.zeros(1, dtype=torch.int64, device=key)
+    return t
+
+
 def dropout_mask(B, H, Lq, Lk, p, seed, device):
     """The keep mask the kernels use (bool [B, H, Lq, Lk]); for tests."""
     m = torch.empty(B * H, Lq, Lk, dtype=torch.uint8, device=device)
-    _lib.call("bfhip_attn_dropout_mask", B, H, Lq, Lk, float(p), seed, m.data_ptr(), _lib.stream_of(m))
+    _lib.call("bfhip_attn_dropout_mask", B, H, Lq, Lk, float(p), seed, step_counter(device).data_ptr(), m.data_ptr(),
+              _lib.stream_of(m))
     return m.view(B, H, Lq, Lk).bool()
 
 
@@ -55,7 +70,7 @@ class _CrossAttention(torch.autograd.Function):
         ws = _workspace(q, nbytes, stream)
         scale = 1.0 / math.sqrt(E // H)
         _lib.call("bfhip_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), B, H, Lq, Lk, scale, dropout_p, seed,
-                  o.data_ptr(), lse.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                  step_counter(q.device).data_ptr(), o.data_ptr(), lse.data_ptr(), ws.data_ptr(), ws.numel(), stream)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.cfg = (H, dropout_p, seed, scale)
         return o
@@ -73,7 +88,8 @@ class _CrossAttention(torch.autograd.Function):
         stream = _lib.stream_of(q)
         ws = _workspace(q, _lib.call_size("bfhip_attn_workspace_bytes", B, H, Lq, Lk), stream)
         _lib.call("bfhip_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), B, H,
-                  Lq, Lk, scale, dropout_p, seed, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                  Lq, Lk, scale, dropout_p, seed, step_counter(q.device).data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                  ws.data_ptr(), ws.numel(), stream)
         return dq, dk, dv, None, None, None
 
 

@@ -257,7 +257,8 @@ class BEVFusion(nn.Module):
 
     def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):
         """BF/bevfusion.py:387-401: dict of the head's losses (the depth loss is computed but not added, :392)."""
-        metas = [getattr(d, "metainfo", None) for d in batch_data_samples]
+        from .head_targets import PackedGT
+        metas = None if isinstance(batch_data_samples, PackedGT) else [getattr(d, "metainfo", None) for d in batch_data_samples]
         feats, _ = self.extract_feat(batch_inputs_dict, metas)
         return dict(self.bbox_head.loss(feats, batch_data_samples))
 

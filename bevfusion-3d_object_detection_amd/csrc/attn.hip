@@ -53,7 +53,13 @@ __device__ __forceinline__ bool keep(unsigned long long seed, unsigned row_base,
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
 
-struct Dims { int B, H, Lq, Lk, E, nchunk; float scale; unsigned thresh24; float inv_keep; unsigned long long seed; };
+struct Dims { int B, H, Lq, Lk, E, nchunk; float scale; unsigned thresh24; float inv_keep; unsigned long long seed;
+              const unsigned long long *seed_dev; };
+// seed_dev (optional): a device-side call counter mixed into the host seed -- a captured hipGraph replays the same host
+// arguments every step, the counter (advanced inside the graph) still gives every step its own dropout mask
+__device__ __forceinline__ unsigned long long eff_seed(const Dims &dm) {
+  return dm.seed_dev ? dm.seed + *dm.seed_dev * 0xD1B54A32D192ED03ull : dm.seed;
+}
 
 // ---------------------------------------------------------------------------------------------------- LSE
 // partial[(bh * nchunk + c) * Lq + q] = (m, l) of chunk c
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const bf16_t *__restrict_
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float p = (kbase + i < dm.Lk && q < dm.Lq) ? __expf(s[i] * dm.scale - lq_[t]) : 0.f;
-        if (DROP) p = keep(dm.seed, ((unsigned)bh * dm.Lq + q) * dm.Lk, kbase + i, dm.thresh24) ? p * dm.inv_keep : 0.f;
+        if (DROP) p = keep(eff_seed(dm), ((unsigned)bh * dm.Lq + q) * dm.Lk, kbase + i, dm.thresh24) ? p * dm.inv_keep : 0.f;
         pa[i] = (short)f2bf(p);
       }
       o[t] = MFMA16(pa, vb, o[t]);  // O[q = t*16 + lg*4 + i][dv = ln]
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *__restrict_
         float p = ok ? __expf(st[i] * dm.scale - lq1) : 0.f;
         float da = dat[i], a = p;
         if (DROP) {
-          const bool kp = keep(dm.seed, rb, kbase + i, dm.thresh24);
+          const bool kp = keep(eff_seed(dm), rb, kbase + i, dm.thresh24);
           da = kp ? da * dm.inv_keep : 0.f;
           a = kp ? p * dm.inv_keep : 0.f;
         }
@@ -337,10 +343,11 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(Dims dm, unsigned char *
   int key = (int)(t % dm.Lk);
   long long r = t / dm.Lk;
   int q = (int)(r % dm.Lq), bh = (int)(r / dm.Lq);
-  mask[t] = keep(dm.seed, ((unsigned)bh * dm.Lq + q) * dm.Lk, key, dm.thresh24) ? 1 : 0;
+  mask[t] = keep(eff_seed(dm), ((unsigned)bh * dm.Lq + q) * dm.Lk, key, dm.thresh24) ? 1 : 0;
 }
 
-inline int make_dims(int B, int H, int Lq, int Lk, float scale, float dropout_p, unsigned long long seed, Dims &dm) {
+inline int make_dims(int B, int H, int Lq, int Lk, float scale, float dropout_p, unsigned long long seed,
+                     const unsigned long long *seed_dev, Dims &dm) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lq > kMaxQT * 16 || Lk <= 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return -1;
   dm.B = B; dm.H = H; dm.Lq = Lq; dm.Lk = Lk; dm.E = H * kD;
   dm.nchunk = (Lk + kChunk - 1) / kChunk;
@@ -348,6 +355,7 @@ inline int make_dims(int B, int H, int Lq, int Lk, float scale, float dropout_p,
   dm.thresh24 = (unsigned)(dropout_p * 16777216.0f);
   dm.inv_keep = 1.0f / (1.0f - dropout_p);
   dm.seed = seed;
+  dm.seed_dev = seed_dev;
   return 0;
 }
 
@@ -365,11 +373,11 @@ BFHIP_EXPORT size_t bfhip_attn_workspace_bytes(int B, int H, int Lq, int Lk) {
 }
 
 BFHIP_EXPORT int bfhip_attn_fwd(const void *Q, const void *K, const void *V, int B, int H, int Lq, int Lk, float scale,
-                                float dropout_p, unsigned long long seed, void *O, float *lse, void *workspace,
+                                float dropout_p, unsigned long long seed, const unsigned long long *seed_dev, void *O, float *lse, void *workspace,
                                 size_t workspace_bytes, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   Dims dm;
-  BFHIP_REQUIRE(make_dims(B, H, Lq, Lk, scale, dropout_p, seed, dm) == 0, "attn_fwd: unsupported sizes B=%d H=%d Lq=%d Lk=%d (Lq <= 256, head dim 16)", B, H, Lq, Lk);
+  BFHIP_REQUIRE(make_dims(B, H, Lq, Lk, scale, dropout_p, seed, seed_dev, dm) == 0, "attn_fwd: unsupported sizes B=%d H=%d Lq=%d Lk=%d (Lq <= 256, head dim 16)", B, H, Lq, Lk);
   BFHIP_REQUIRE(Q && K && V && O && lse, "attn_fwd: null pointer");
   BFHIP_REQUIRE(((uintptr_t)Q % 8) == 0 && ((uintptr_t)K % 8) == 0 && ((uintptr_t)V % 8) == 0, "attn_fwd: tensors must be 8-byte aligned");
   if (!workspace || workspace_bytes < bfhip_attn_workspace_bytes(B, H, Lq, Lk)) { set_error("attn_fwd: workspace too small"); return BFHIP_E_WORKSPACE; }
@@ -388,10 +396,11 @@ BFHIP_EXPORT int bfhip_attn_fwd(const void *Q, const void *K, const void *V, int
 
 BFHIP_EXPORT int bfhip_attn_bwd(const void *Q, const void *K, const void *V, const void *O, const void *dO, const float *lse,
                                 int B, int H, int Lq, int Lk, float scale, float dropout_p, unsigned long long seed,
-                                void *dQ, void *dK, void *dV, void *workspace, size_t workspace_bytes, void *stream_) {
+                                const unsigned long long *seed_dev, void *dQ, void *dK, void *dV, void *workspace,
+                                size_t workspace_bytes, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   Dims dm;
-  BFHIP_REQUIRE(make_dims(B, H, Lq, Lk, scale, dropout_p, seed, dm) == 0, "attn_bwd: unsupported sizes");
+  BFHIP_REQUIRE(make_dims(B, H, Lq, Lk, scale, dropout_p, seed, seed_dev, dm) == 0, "attn_bwd: unsupported sizes");
   BFHIP_REQUIRE(Q && K && V && O && dO && lse && dQ && dK && dV, "attn_bwd: null pointer");
   if (!workspace || workspace_bytes < bfhip_attn_workspace_bytes(B, H, Lq, Lk)) { set_error("attn_bwd: workspace too small"); return BFHIP_E_WORKSPACE; }
   float *dqpart = (float *)((char *)workspace + align_up((size_t)B * H * dm.nchunk * Lq * sizeof(float2), 256));
@@ -405,9 +414,10 @@ BFHIP_EXPORT int bfhip_attn_bwd(const void *Q, const void *K, const void *V, con
 }
 
 BFHIP_EXPORT int bfhip_attn_dropout_mask(int B, int H, int Lq, int Lk, float dropout_p, unsigned long long seed,
+                                         const unsigned long long *seed_dev,
                                          unsigned char *mask, void *stream_) {
   Dims dm;
-  BFHIP_REQUIRE(make_dims(B, H, Lq, Lk, 1.f, dropout_p, seed, dm) == 0 && mask, "attn_dropout_mask: bad arguments");
+  BFHIP_REQUIRE(make_dims(B, H, Lq, Lk, 1.f, dropout_p, seed, seed_dev, dm) == 0 && mask, "attn_dropout_mask: bad arguments");
   long long total = (long long)B * H * Lq * Lk;
   hipLaunchKernelGGL(attn_mask_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_, dm, mask);
   return check_launch("attn_dropout_mask");

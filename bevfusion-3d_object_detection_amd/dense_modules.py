@@ -453,7 +453,11 @@ class BEVFusionHead(nn.Module):
         from . import head_targets as ht
         tc = self.train_cfg
         dev = preds_dict["center"].device
-        gt_boxes, gt_labels, n_gt, counts = ht.pack_gt(batch_gt_instances_3d, dev)
+        packed = batch_gt_instances_3d if isinstance(batch_gt_instances_3d, ht.PackedGT) else None
+        if packed is not None:
+            gt_boxes, gt_labels, n_gt, counts = packed.boxes, packed.labels, packed.n_gt, packed.counts
+        else:
+            gt_boxes, gt_labels, n_gt, counts = ht.pack_gt(batch_gt_instances_3d, dev)
         P = self.num_proposals
         L = self.num_decoder_layers if self.auxiliary else 1
         vel = preds_dict.get("vel")
@@ -474,7 +478,10 @@ class BEVFusionHead(nn.Module):
         self.assignment_status = torch.stack(statuses) if L > 1 else statuses[0]
         pos_per_sample = [min(c, P) * L for c in counts]  # the Hungarian step matches min(#GT, #proposals) pairs
         num_pos = sum(pos_per_sample)
-        denom = torch.tensor([max(n, 1) for n in pos_per_sample], dtype=torch.float32).to(dev, non_blocking=True)
+        if packed is not None:
+            denom = packed.denom(pos_per_sample)
+        else:
+            denom = torch.tensor([max(n, 1) for n in pos_per_sample], dtype=torch.float32).to(dev, non_blocking=True)
         matched_ious = (ious.sum(1) / denom).mean()
         heatmap = ht.draw_heatmap(gt_boxes, gt_labels, n_gt, self.num_classes, tc["grid_size"], tc["point_cloud_range"],
                                   tc["voxel_size"], tc["out_size_factor"], tc["gaussian_overlap"], tc["min_radius"])
@@ -524,6 +531,9 @@ class BEVFusionHead(nn.Module):
     def loss(self, batch_feats, batch_data_samples):
         """BF/bevfusion_head.py:676-694.  `batch_data_samples`: objects with `.gt_instances_3d` (+ `.metainfo`), or the
         ground truth itself as (boxes, labels) pairs."""
+        from .head_targets import PackedGT
+        if isinstance(batch_data_samples, PackedGT):  # ground truth prepared on the device ahead of the step
+            return self.loss_by_feat(self(batch_feats, None), batch_data_samples)
         gts = [getattr(d, "gt_instances_3d", d) for d in batch_data_samples]
         metas = [getattr(d, "metainfo", None) for d in batch_data_samples]
         return self.loss_by_feat(self(batch_feats, metas), gts)

@@ -26,6 +26,12 @@ from .ops import bev_pool
 from .registry import MODELS
 
 
+def _inverse(m):
+    """torch.inverse without its device -> host read of the LU status (same factorisation; the reference's calibration
+    matrices are never singular): keeps the camera branch free of synchronising calls."""
+    return torch.linalg.inv_ex(m, check_errors=False).inverse
+
+
 def gen_dx_bx(xbound, ybound, zbound):
     """(reference :14-18) dx = step, bx = first cell centre, nx = int((hi-lo)/step)."""
     rows = [xbound, ybound, zbound]
@@ -245,7 +251,7 @@ class BaseViewTransform(nn.Module):
         intrins = camera_intrinsics[..., :3, :3]
         post_rots = img_aug_matrix[..., :3, :3]
         return dict(camera2lidar_rots=camera2lidar[..., :3, :3], camera2lidar_trans=camera2lidar[..., :3, 3],
-                    intrins_inverse=torch.inverse(intrins), post_rots_inverse=torch.inverse(post_rots),
+                    intrins_inverse=_inverse(intrins), post_rots_inverse=_inverse(post_rots),
                     post_trans=img_aug_matrix[..., :3, 3], extra_rots=lidar_aug_matrix[..., :3, :3],
                     extra_trans=lidar_aug_matrix[..., :3, 3])
 
@@ -314,7 +320,7 @@ class BaseDepthTransform(BaseViewTransform):
         with_histogram: also return the un-normalised GT depth-bin counts [B, N, fH, fW, D] of :636-670,
         accumulated in the same pass."""
         if lidar_aug_matrix_inverse is None:
-            lidar_aug_matrix_inverse = torch.inverse(lidar_aug_matrix)
+            lidar_aug_matrix_inverse = _inverse(lidar_aug_matrix)
         B = len(points)
         N = img.shape[1]
         iH, iW = self.image_size

@@ -66,6 +66,24 @@ def pack_gt(batch_gt, device):
     return boxes, labels, n_gt, counts
 
 
+class PackedGT:
+    """Ground truth of a batch already padded and resident on the device (what `pack_gt` builds), for callers that prepare
+    it ahead of the step -- a data loader's prefetch thread, or a captured hipGraph whose replay must not contain host -> device
+    copies.  `BEVFusionHead.loss` / `get_targets` accept it in place of the per-sample list."""
+
+    def __init__(self, batch_gt, device):
+        self.boxes, self.labels, self.n_gt, self.counts = pack_gt(batch_gt, device)
+        self._denoms = {}
+
+    def denom(self, pos_per_sample):
+        """max(#positives, 1) per sample as a device tensor (cached: the counts are host constants of this batch)."""
+        key = tuple(pos_per_sample)
+        t = self._denoms.get(key)
+        if t is None:
+            t = self._denoms[key] = torch.tensor([max(n, 1) for n in pos_per_sample], dtype=torch.float32).to(self.boxes.device)
+        return t
+
+
 # ----------------------------------------------------------------------------------------------- box coder
 @MODELS.register_module()
 class TransFusionBBoxCoder:

@@ -341,13 +341,15 @@ int bfhip_xty(const void *X, const void *Y, long long K, int M, int N, int dtype
  * --------------------------------------------------------------------------------------- */
 size_t bfhip_attn_workspace_bytes(int B, int H, int Lq, int Lk);
 int bfhip_attn_fwd(const void *Q, const void *K, const void *V, int B, int H, int Lq, int Lk, float scale,
-                   float dropout_p, unsigned long long seed, void *O, float *lse, void *workspace,
-                   size_t workspace_bytes, void *stream);
+                   float dropout_p, unsigned long long seed, const unsigned long long *seed_dev, void *O, float *lse,
+                   void *workspace, size_t workspace_bytes, void *stream);
 int bfhip_attn_bwd(const void *Q, const void *K, const void *V, const void *O, const void *dO, const float *lse, int B,
-                   int H, int Lq, int Lk, float scale, float dropout_p, unsigned long long seed, void *dQ, void *dK,
-                   void *dV, void *workspace, size_t workspace_bytes, void *stream);
+                   int H, int Lq, int Lk, float scale, float dropout_p, unsigned long long seed,
+                   const unsigned long long *seed_dev, void *dQ, void *dK, void *dV, void *workspace, size_t workspace_bytes,
+                   void *stream);
+/* seed_dev (optional, all three): device u64 call counter mixed into the seed (a replayed hipGraph repeats its host arguments) */
 int bfhip_attn_dropout_mask(int B, int H, int Lq, int Lk, float dropout_p, unsigned long long seed,
-                            unsigned char *mask, void *stream);
+                            const unsigned long long *seed_dev, unsigned char *mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Bilinear 2x upsampling of channels-last maps [B, H, W, C] -> [B, 2H, 2W, C] (f32 | bf16), torch's align_corners=False
