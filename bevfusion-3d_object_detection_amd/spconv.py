@@ -198,6 +198,8 @@ class CapacityMonitor:
 
     def poll(self):
         """The counts of the last submitted forward if they have arrived, else None."""
+        if torch.cuda.is_current_stream_capturing():
+            return None
         if self.pending and self.event.query():
             self.pending = False
             return self.pinned.tolist()
