@@ -479,7 +479,7 @@ class BEVFusionHead(nn.Module):
         pos_per_sample = [min(c, P) * L for c in counts]  # the Hungarian step matches min(#GT, #proposals) pairs
         num_pos = sum(pos_per_sample)
         if packed is not None:
-            denom = packed.denom(pos_per_sample)
+            denom = packed.denom(P, L)
         else:
             denom = torch.tensor([max(n, 1) for n in pos_per_sample], dtype=torch.float32).to(dev, non_blocking=True)
         matched_ious = (ious.sum(1) / denom).mean()

@@ -73,15 +73,10 @@ class PackedGT:
 
     def __init__(self, batch_gt, device):
         self.boxes, self.labels, self.n_gt, self.counts = pack_gt(batch_gt, device)
-        self._denoms = {}
 
-    def denom(self, pos_per_sample):
-        """max(#positives, 1) per sample as a device tensor (cached: the counts are host constants of this batch)."""
-        key = tuple(pos_per_sample)
-        t = self._denoms.get(key)
-        if t is None:
-            t = self._denoms[key] = torch.tensor([max(n, 1) for n in pos_per_sample], dtype=torch.float32).to(self.boxes.device)
-        return t
+    def denom(self, num_proposals, num_layers):
+        """max(#positives, 1) per sample, computed on the device from n_gt (no host -> device copy inside the step)."""
+        return (torch.clamp(self.n_gt, max=num_proposals) * num_layers).clamp(min=1).float()
 
 
 # ----------------------------------------------------------------------------------------------- box coder
