@@ -257,7 +257,7 @@ class _ModelWorkload:
         self.opt.zero_grad() if self.master_weights else self.opt.zero_grad(set_to_none=True)
         loss = self._forward_backward(self.gts)
         self._update()
-        return loss
+        return loss.detach()  # a caller holding the loss must not keep the step's autograd nodes alive
 
     def step(self):
         """Eager by default.  BENCH_GRAPH=1: after three eager steps (row capacities of the LiDAR branch learnt, workspaces
@@ -290,7 +290,7 @@ class _ModelWorkload:
             loss = self._forward_backward(self._gts_dev)
             if self._graph_has_update:
                 self._update()
-        self._graph, self._static_loss = g, loss
+        self._graph, self._static_loss = g, loss.detach()
 
     # ---- algorithmic work of the hand-written ops of ONE step (for the roofline object)
     def collect_work(self):

@@ -47,6 +47,29 @@ def main(path, top=45):
             table[key][1] += 1
     busy = sum(v[0] for v in cat.values())
     print("step window %.2f ms, GPU busy %.2f ms, %d kernels" % ((t1 - t0) / 1e6, busy / 1e6, len(win)))
+    # per queue: busy time; over all queues: time covered by at least one kernel (the rest of the window is idle GPU)
+    per_q = collections.defaultdict(lambda: [0, 0])
+    for r in win:
+        q = r.get("Queue_Id", "?")
+        per_q[q][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        per_q[q][1] += 1
+    for q, (d, n) in sorted(per_q.items(), key=lambda kv: -kv[1][0]):
+        print("queue %-6s n=%5d busy=%8.3f ms" % (q, n, d / 1e6))
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in win)
+    cov, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    gaps = []
+    for a, b in iv[1:]:
+        if a > cur_e:
+            cov += cur_e - cur_s
+            gaps.append(a - cur_e)
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    cov += cur_e - cur_s
+    gaps.sort()
+    print("covered by >= 1 kernel: %.2f ms; idle: %.2f ms in %d gaps (median %.1f us, p90 %.1f us, max %.1f us)"
+          % (cov / 1e6, ((t1 - t0) - cov) / 1e6, len(gaps), gaps[len(gaps) // 2] / 1e3 if gaps else 0,
+             gaps[int(len(gaps) * 0.9)] / 1e3 if gaps else 0, gaps[-1] / 1e3 if gaps else 0))
     for k, (d, n) in sorted(cat.items(), key=lambda kv: -kv[1][0]):
         print("%-48s n=%5d ms=%8.3f" % (k, n, d / 1e6))
     print("---- top kernels")
