@@ -38,6 +38,7 @@ struct ConvGeom {
   int OH, OW;
   int KH, KW, stride, pad, dil;
   int transposed;  // 0: src = row * stride - pad + k * dil     1: t = row + pad - k * dil, src = t / stride if divisible
+  int sshift, smask;  // transposed mode: stride = 1 << sshift, smask = stride - 1
   int nq;          // KH * KW * C / 8: number of 16-byte pieces along K
   long long M;     // N * OH * OW
   int Kout;        // GEMM columns (output channels of this GEMM)
@@ -66,51 +67,67 @@ __device__ __forceinline__ void build_tap_table(unsigned *taps, const ConvGeom &
   }
 }
 
-// source address of piece (dh, dw, ci) for the row whose bases are (nb, hb, wb); nullptr -> zero page
+// source address of piece (dh, dw, ci) for the row whose bases are (nb, hb, wb); out of range -> zero page.
+// Kept short on purpose: it runs once per 16-byte piece (4 + NB times per wave and K step) beside 16 MFMAs -- no integer
+// division (transposed strides are powers of two: shift + mask), 32-bit element offsets (tensors < 2^31 elements).
+template <bool TR>
 __device__ __forceinline__ const bf16_t *piece_src(const bf16_t *x, const ConvGeom &g, bool row_ok, int nb, int hb, int wb,
                                                    unsigned info) {
   const int dh = info >> 24, dw = (info >> 16) & 0xff, ci = info & 0xffff;
   int ih, iw;
   bool ok = row_ok;
-  if (!g.transposed) {
+  if (!TR) {
     ih = hb + dh;
     iw = wb + dw;
   } else {
-    int th = hb - dh, tw = wb - dw;
-    ok = ok && th >= 0 && tw >= 0;
-    if (g.stride == 1) { ih = th; iw = tw; }
-    else {
-      ih = th / g.stride;
-      iw = tw / g.stride;
-      ok = ok && ih * g.stride == th && iw * g.stride == tw;
-    }
+    const int th = hb - dh, tw = wb - dw;
+    ok = ok && ((th | tw) >= 0) && (((th | tw) & g.smask) == 0);
+    ih = th >> g.sshift;
+    iw = tw >> g.sshift;
   }
   ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-  return ok ? x + ((size_t)(nb + ih * g.W + iw) * g.ldx + ci) : (const bf16_t *)g_zero_page;
+  const unsigned off = (unsigned)(nb + ih * g.W + iw) * (unsigned)g.ldx + (unsigned)ci;
+  return ok ? x + off : (const bf16_t *)g_zero_page;
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
-// LDS: A[2][128][64] bf16, B[2][BN][64] bf16, tap table.  Rows are 128 bytes (8 pieces); piece c of row r sits at
-// position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 lane group touches land on 16 distinct 16-byte slots.
-template <int WN, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt,
-                                                            const float *__restrict__ bias, void *__restrict__ y,
-                                                            float *__restrict__ stat_partial, ConvGeom g, int tiles_m,
-                                                            int tiles_n) {
-  constexpr int BN = WN * 64, BM = 128, BK = 64;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+// Tile (WM * 64) rows x (WN * 64) columns, WM * 2 waves (wave tile 64 x WN*32), a ring of STAGES LDS stages of one K step
+// (64 bf16) each.  Rows are 128 bytes (8 pieces); piece c of row r sits at position c ^ ((r >> 1) & 7): the 16 rows a
+// ds_read_b128 lane group touches land on 16 distinct 16-byte slots.
+//   <2, WN, 2>: 128-row tiles, 256 threads, two stages, two workgroups per CU (small problems, narrow outputs)
+//   <4, 2, 3> : 256 x 128 tiles, 512 threads, three stages = TWO K steps (96 KB) in flight per CU under the MFMAs of the
+//               third: at ~64 B/clk/CU of operand traffic and ~1500 cycles of loaded L2 latency that is what it takes to keep
+//               the DMA queue from draining (Little's law); the waits are counted (`vmcnt(GL)` leaves the next stage's GL
+//               DMA instructions in flight) and the barrier is the raw s_barrier, which does not drain them.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int WN, int STAGES, bool OUT_F32, bool TR>
+__global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt,
+                                                                 const float *__restrict__ bias, void *__restrict__ y,
+                                                                 float *__restrict__ stat_partial, ConvGeom g, int tiles_m,
+                                                                 int tiles_n) {
+  constexpr int NTHREADS = WM * 128, NWAVES = WM * 2;
+  constexpr int BN = WN * 64, BM = WM * 64, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, S_BYTES = A_BYTES + B_BYTES;
+  constexpr int NB = (BN / 8) / NWAVES;  // B DMA instructions per wave and stage (8 rows each)
+  constexpr int GL = 4 + NB;             // DMA instructions per wave and stage
+  static_assert(NB >= 1 && NB * 8 * NWAVES == BN, "B tile must split into whole DMA instructions");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  unsigned char *sA = smem, *sB = smem + 2 * A_BYTES;
-  unsigned *taps = (unsigned *)(smem + 2 * A_BYTES + 2 * B_BYTES);
+  unsigned *taps = (unsigned *)(smem + STAGES * S_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles_m * tiles_n);
   const int tn = (int)(lb % tiles_n), tm = (int)(lb / tiles_n);
   const long long m0 = (long long)tm * BM;
   const int n0 = tn * BN;
 
-  build_tap_table(taps, g);
+  for (int q = tid; q < g.nq; q += NTHREADS) {
+    int k = q * 8;
+    int tap = k / g.C, ci = k - tap * g.C;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    taps[q] = ((unsigned)(kh * g.dil) << 24) | ((unsigned)(kw * g.dil) << 16) | (unsigned)ci;
+  }
 
-  // ---- per-lane staging state: 4 A rows (one per DMA instruction) and WN*2 B rows
+  // ---- per-lane staging state: 4 A rows (one per DMA instruction) and NB B rows; every wave stages 32 A rows
   const int lrow = lane >> 3, lpos = lane & 7;
   int nb[4], hb[4], wb[4];
   bool rok[4];
@@ -123,31 +140,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t *__rest
     int rem = (int)(mm - (long long)n * g.OH * g.OW);
     int oh = rem / g.OW, ow = rem - oh * g.OW;
     nb[i] = n * g.H * g.W;
-    hb[i] = g.transposed ? oh + g.pad : oh * g.stride - g.pad;
-    wb[i] = g.transposed ? ow + g.pad : ow * g.stride - g.pad;
+    hb[i] = TR ? oh + g.pad : oh * g.stride - g.pad;
+    wb[i] = TR ? ow + g.pad : ow * g.stride - g.pad;
   }
-  const bf16_t *wrow[WN * 2];
+  const bf16_t *wrow[NB];
 #pragma unroll
-  for (int i = 0; i < WN * 2; ++i) {
-    int co = n0 + w * (WN * 16) + i * 8 + lrow;
+  for (int i = 0; i < NB; ++i) {
+    int co = n0 + w * (NB * 8) + i * 8 + lrow;
     wrow[i] = co < g.Kout ? wt + (size_t)co * g.ldw : nullptr;
   }
   __syncthreads();  // tap table ready
 
   const int nt = (g.nq + 7) >> 3;
-  auto stage = [&](int t, int buf) {
-    unsigned char *dA = sA + buf * A_BYTES + (w * 32) * 128;
-    unsigned char *dB = sB + buf * B_BYTES + (w * (WN * 16)) * 128;
+  auto stage = [&](int t, int buf) {  // exactly GL DMA instructions per wave (the counted waits rely on it)
+    unsigned char *dA = smem + buf * S_BYTES + (w * 32) * 128;
+    unsigned char *dB = smem + buf * S_BYTES + A_BYTES + (w * (NB * 8)) * 128;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int swz = (i * 4 + (lane >> 4)) & 7;  // ((row >> 1) & 7) of row = w*32 + i*8 + lrow
       const int q = t * 8 + (lpos ^ swz);
-      const bf16_t *src = q < g.nq ? piece_src(x, g, rok[i], nb[i], hb[i], wb[i], taps[q]) : (const bf16_t *)g_zero_page;
+      const bf16_t *src = q < g.nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q]) : (const bf16_t *)g_zero_page;
       glds16(src, dA + i * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < WN * 2; ++i) {
-      const int swz = (i * 4 + (lane >> 4)) & 7;  // rows of B start at multiples of 16 per wave: same form
+    for (int i = 0; i < NB; ++i) {
+      const int swz = ((w * (NB * 8) + i * 8 + lrow) >> 1) & 7;
       const int q = t * 8 + (lpos ^ swz);
       const bf16_t *src = (wrow[i] && q < g.nq) ? wrow[i] + (size_t)q * 8 : (const bf16_t *)g_zero_page;
       glds16(src, dB + i * 1024);
@@ -164,15 +181,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t *__rest
 
   const int wm = w >> 1, wn = w & 1;
   const int l31 = lane & 31, lh = lane >> 5, rswz = (lane >> 1) & 7;  // ((row >> 1) & 7) of row = 32*j + l31
-  const int aoff = (wm * 64 + l31) * 128, boff = (wn * (WN * 32) + l31) * 128;
+  const int aoff = (wm * 64 + l31) * 128, boff = A_BYTES + (wn * (WN * 32) + l31) * 128;
 
-  stage(0, 0);
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nt) stage(s0, s0);
+  int buf = 0, nbuf = STAGES - 1;  // stage holding step t / stage the next DMA goes to
   for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nt) stage(t + 1, buf ^ 1);
-    const unsigned char *pA = sA + buf * A_BYTES + aoff, *pB = sB + buf * B_BYTES + boff;
+    // step t must have landed; the DMA of the (up to STAGES - 2) later steps stays in flight
+    if (STAGES == 2 || nt - 1 - t == 0) wait_vmcnt<0>();
+    else if (STAGES == 3 || nt - 1 - t == 1) wait_vmcnt<GL>();
+    else wait_vmcnt<2 * GL>();
+    __builtin_amdgcn_s_barrier();  // all of step t is in LDS; every wave is done reading step t - 1
+    if (t + STAGES - 1 < nt) stage(t + STAGES - 1, nbuf);
+    const unsigned char *pA = smem + buf * S_BYTES + aoff, *pB = smem + buf * S_BYTES + boff;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int pos = ((2 * ks + lh) ^ rswz) << 4;
@@ -186,12 +208,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t *__rest
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
+    buf = buf + 1 == STAGES ? 0 : buf + 1;
+    nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
   }
   __syncthreads();  // every wave is done with the staging buffers: reuse them for the epilogue
 
-  // ---- BatchNorm statistics of the raw accumulators (rows beyond M are exact zeros): per-column sum / sum of squares
+  // ---- BatchNorm statistics of the raw accumulators (rows beyond M are exact zeros): per-column sum / sum of squares,
+  //      one partial row per 128 rows of the tile
   if (stat_partial) {
-    float *sred = (float *)(smem);  // [2 (wm)][BN][2]
+    float *sred = (float *)(smem);  // [WM][BN][2]
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
       float s = 0.f, s2 = 0.f;
@@ -208,15 +233,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t *__rest
       }
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < g.Kout) {
-      float s = sred[tid * 2] + sred[(BN + tid) * 2], s2 = sred[tid * 2 + 1] + sred[(BN + tid) * 2 + 1];
-      stat_partial[((size_t)tm * 2 + 0) * g.Kout + n0 + tid] = s;
-      stat_partial[((size_t)tm * 2 + 1) * g.Kout + n0 + tid] = s2;
+    const int total_rows = (int)((g.M + 127) / 128);
+    for (int e = tid; e < (WM / 2) * BN; e += NTHREADS) {
+      const int half = e / BN, col = e - half * BN;
+      const int prow = tm * (WM / 2) + half;
+      if (n0 + col < g.Kout && prow < total_rows) {
+        const float *p0 = sred + ((half * 2) * BN + col) * 2, *p1 = sred + ((half * 2 + 1) * BN + col) * 2;
+        stat_partial[((size_t)prow * 2 + 0) * g.Kout + n0 + col] = p0[0] + p1[0];
+        stat_partial[((size_t)prow * 2 + 1) * g.Kout + n0 + col] = p0[1] + p1[1];
+      }
     }
     __syncthreads();
   }
 
-  // ---- output: accumulators -> LDS [128][BN] (row-major) -> 16-byte coalesced stores
+  // ---- output: accumulators -> LDS [BM][BN] (row-major) -> 16-byte coalesced stores
   constexpr int ESZ = OUT_F32 ? 4 : 2;
   constexpr int ROWB = BN * ESZ;
 #pragma unroll
@@ -236,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t *__rest
   __syncthreads();
   constexpr int CPR = ROWB / 16;  // 16-byte pieces per row
   constexpr int EPC = 16 / ESZ;   // elements per piece
-  for (int idx = tid; idx < BM * CPR; idx += 256) {
+  for (int idx = tid; idx < BM * CPR; idx += NTHREADS) {
     const int row = idx / CPR, c = idx - row * CPR;
     const long long m = m0 + row;
     const int col = n0 + c * EPC;
@@ -458,11 +488,12 @@ __global__ __launch_bounds__(256) void conv_weight_transpose_kernel(const bf16_t
 }
 
 bool geom_ok(int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil) {
-  return N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C < 65536 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dil > 0 &&
+  return N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C < 65536 && KH > 0 && KW > 0 && stride > 0 &&
+         (stride & (stride - 1)) == 0 /* the data gradient shifts instead of dividing */ && pad >= 0 && dil > 0 &&
          (KH - 1) * dil < 256 && (KW - 1) * dil < 256 && (long long)KH * KW * C / 8 <= 8192;
 }
 
-size_t igemm_lds_bytes(int WN, int nq) { return (size_t)2 * 128 * 128 + (size_t)2 * WN * 64 * 128 + (size_t)nq * 4; }
+size_t igemm_lds_bytes(int WM, int WN, int stages, int nq) { return (size_t)stages * (WM + WN) * 64 * 128 + (size_t)nq * 4; }
 
 }  // namespace
 }  // namespace bfhip
@@ -479,21 +510,32 @@ BFHIP_EXPORT int bfhip_conv2d_stat_rows(int N, int OH, int OW) { return ceil_div
 static int launch_igemm(const void *x, const void *wt, const float *bias, void *y, float *stat_partial, ConvGeom g, int out_f32,
                         hipStream_t s, const char *what) {
   const int WN = g.Kout > 64 ? 2 : 1;
-  const int tiles_m = ceil_div(g.M, 128), tiles_n = ceil_div(g.Kout, WN * 64);
-  const size_t lds = igemm_lds_bytes(WN, g.nq);
+  // 256 x 128 tiles with a three-stage ring (two K steps of DMA in flight, counted vmcnt, raw s_barrier) were measured
+  // against the 128-row tiles below on the 180 x 180 BEV layers: 0.301 vs 0.296 ms (336 -> 256), 0.072 vs 0.069 ms
+  // (128 -> 128) -- no gain: at a 64 x 64 wave tile the LDS is ~87 % busy at the MFMA peak either way (128 KB of fragment
+  // reads + 48 KB of DMA writes per K step and CU), so deeper prefetch has nothing to expose.  Opt-in for experiments only.
+  static const int force_big = getenv("BFHIP_CONV_BIG_TILES") ? 1 : 0;
+  const bool big = WN == 2 && force_big && ceil_div(g.M, 256) * ceil_div(g.Kout, 128) >= 192;
+  const int WM = big ? 4 : 2, stages = big ? 3 : 2;
+  const int tiles_m = ceil_div(g.M, WM * 64), tiles_n = ceil_div(g.Kout, WN * 64);
+  const size_t lds = igemm_lds_bytes(WM, WN, stages, g.nq);
   dim3 grid((unsigned)((long long)tiles_m * tiles_n));
-#define BFHIP_IG(WNV, F32)                                                                                              \
+#define BFHIP_IG(WMV, WNV, ST, F32, TRV)                                                                                \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<WNV, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2); \
+      (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<WMV, WNV, ST, F32, TRV>,                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ST == 3 ? 160 * 1024 : 80 * 1024);         \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_igemm_kernel<WNV, F32>), grid, dim3(256), lds, s, (const bf16_t *)x, (const bf16_t *)wt, bias, y, \
-                       stat_partial, g, tiles_m, tiles_n);                                                             \
+    hipLaunchKernelGGL((conv_igemm_kernel<WMV, WNV, ST, F32, TRV>), grid, dim3(WMV * 128), lds, s, (const bf16_t *)x,  \
+                       (const bf16_t *)wt, bias, y, stat_partial, g, tiles_m, tiles_n);                                \
   } while (0)
-  if (WN == 2) { if (out_f32) BFHIP_IG(2, true); else BFHIP_IG(2, false); }
-  else { if (out_f32) BFHIP_IG(1, true); else BFHIP_IG(1, false); }
+#define BFHIP_IG2(WMV, WNV, ST, F32) do { if (g.transposed) BFHIP_IG(WMV, WNV, ST, F32, true); else BFHIP_IG(WMV, WNV, ST, F32, false); } while (0)
+  if (big) { if (out_f32) BFHIP_IG2(4, 2, 3, true); else BFHIP_IG2(4, 2, 3, false); }
+  else if (WN == 2) { if (out_f32) BFHIP_IG2(2, 2, 2, true); else BFHIP_IG2(2, 2, 2, false); }
+  else { if (out_f32) BFHIP_IG2(2, 1, 2, true); else BFHIP_IG2(2, 1, 2, false); }
+#undef BFHIP_IG2
 #undef BFHIP_IG
   return check_launch(what);
 }
@@ -513,10 +555,11 @@ BFHIP_EXPORT int bfhip_conv2d_fwd(const void *x, int ldx, const void *w, const f
   g.OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   g.OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   BFHIP_REQUIRE(g.OH > 0 && g.OW > 0, "conv2d_fwd: empty output");
-  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 0;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 0; g.sshift = 0; g.smask = 0;
   g.nq = KH * KW * Cin / 8;
   g.M = (long long)N * g.OH * g.OW;
   g.Kout = Cout; g.ldw = KH * KW * Cin; g.ldy = ldy;
+  BFHIP_REQUIRE((long long)N * H * W * ldx < (1LL << 31), "conv2d_fwd: tensors of 2^31 elements or more are not supported");
   return launch_igemm(x, w, bias, y, stat_partial, g, out_f32, (hipStream_t)stream_, "conv2d_fwd");
 }
 
@@ -542,6 +585,9 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
   g.N = N; g.H = OH; g.W = OW; g.C = Cout; g.ldx = ldg;   // gathered tensor = dy
   g.OH = H; g.OW = W;                                    // GEMM rows = input pixels
   g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 1;
+  BFHIP_REQUIRE((stride & (stride - 1)) == 0, "conv2d_dgrad: the stride must be a power of two (got %d)", stride);
+  g.sshift = __builtin_ctz((unsigned)stride); g.smask = stride - 1;
+  BFHIP_REQUIRE((long long)N * OH * OW * ldg < (1LL << 31), "conv2d_dgrad: tensors of 2^31 elements or more are not supported");
   g.nq = KH * KW * Cout / 8;
   g.M = (long long)N * H * W;
   g.Kout = Cin; g.ldw = KH * KW * Cout; g.ldy = ldx;
@@ -595,7 +641,7 @@ BFHIP_EXPORT int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int 
   g.N = N; g.H = H; g.W = W; g.C = Cin; g.ldx = ldx;
   g.OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   g.OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
-  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 0;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 0; g.sshift = 0; g.smask = 0;
   g.nq = KH * KW * Cin / 8;
   g.M = (long long)N * g.OH * g.OW;
   g.Kout = Cout; g.ldw = 0; g.ldy = 0;
