@@ -64,6 +64,7 @@ def _weight_ohwi(w):
 class _Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, emit_stats):
+        ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the (non-differentiable) statistics output
         x = _as_nhwc_bf16(x)
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = weight.shape
@@ -90,6 +91,8 @@ class _Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dpartial):
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None, None, None, None
         stride, pad, dil = ctx.geom
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = weight.shape

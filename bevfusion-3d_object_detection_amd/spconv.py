@@ -206,9 +206,13 @@ class CapacityMonitor:
         return None
 
 
+CAPACITY_SLACK = float(os.environ.get("BFHIP_CAPACITY_SLACK", "1.25"))
+
+
 def round_capacity(n):
-    """Row capacity for an observed count n: 1.5x + 4096, rounded up to 4096 (grow-only at the call sites)."""
-    return (int(n) * 3 // 2 + 4096 + 4095) // 4096 * 4096
+    """Row capacity for an observed count n: slack x n + 2048, rounded up to 2048 (grow-only at the call sites).  Frame-to-
+    frame occupancy of one drive varies by well under 25 %; an overflow is detected (CapacityMonitor), reported and grown."""
+    return (int(int(n) * CAPACITY_SLACK) + 2048 + 2047) // 2048 * 2048
 
 
 def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, plan=None):
