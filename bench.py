@@ -199,6 +199,8 @@ class _ModelWorkload:
         self.step_model = self.model
         self.master_weights = self.amp and os.environ.get("BENCH_MASTER_WEIGHTS", "1") == "1"
         self.use_graph = os.environ.get("BENCH_GRAPH", "0") == "1"
+        if self.use_graph:
+            self.model.static_lidar = True  # a captured step cannot contain the exact path's host reads
         if self.master_weights:
             # conv / linear weights held in bf16 (what the kernels consume), fp32 masters in the optimizer: same arithmetic
             # as autocast without ~320 per-step cast launches; DDP then reduces bf16 gradients for these layers

@@ -60,8 +60,11 @@ class BEVFusion(nn.Module):
         self.lidar_side_stream = False  # opt-in: run the LiDAR branch on a second HIP stream (bench.py enables it)
         self._side_stream = None
         # static capacity mode of the LiDAR branch: buffers sized by (grow-only) bounds learnt from earlier frames, every row
-        # count on the device, ZERO host reads per forward; the first forward runs the exact path to learn them
-        self.static_lidar = os.environ.get("BFHIP_STATIC_LIDAR", "1") == "1"
+        # count on the device, ZERO host reads per forward; the first forward runs the exact path to learn them.
+        # Opt-in (BFHIP_STATIC_LIDAR=1, or a captured hipGraph, which needs it): on the side stream the two host reads of the
+        # exact path cost nothing measurable, while capacity-sized buffers add 0.6 ms (slack 1.05) to 1.3 ms (slack 1.5) of
+        # GPU work per batch-4 step (36.9 exact vs 37.5 / 37.7 / 38.2 ms, same box, bench.py `full`)
+        self.static_lidar = os.environ.get("BFHIP_STATIC_LIDAR", "0") == "1"
         self._voxel_cap = None
         self._voxel_monitor = None
 

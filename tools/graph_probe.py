@@ -18,6 +18,7 @@ def run(part):
     dev = torch.device("cuda:0")
     wl = bench.FullModel(dev, int(os.environ.get("PROBE_BATCH", "2")), 40000)
     wl.use_graph = False
+    wl.model.static_lidar = True
     if os.environ.get("PROBE_WORK"):
         wl.collect_work()
     wl.model.lidar_side_stream = os.environ.get("PROBE_SIDE", "0") == "1"
