@@ -213,6 +213,21 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const int *__restrict
   lengths[k] = next - starts[k];
 }
 
+// Camera-major processing order of the intervals.  A BEV cell's members are frustum points of (almost always) ONE camera,
+// and each feature row (320 B) is shared by the 118 depth points of its ray -- i.e. by cells strung out along the ray, far
+// apart in rank order (x-major): walked in rank order the 21.6 MB row table of a batch misses the 4 MiB per-XCD L2 on nearly
+// every gather (PMC: 1.24 GB fetched for 62 MB of algorithmic bytes per launch).  Keyed by (sample, camera) of the first
+// member and sorted stably (rank order inside a camera), every XCD walks ~3 cameras whose rows (0.9 MB each) stay in ITS
+// L2.  Only the order in which cells are produced changes; the sum inside a cell keeps rank order (bit-identical output).
+__global__ __launch_bounds__(256) void plan_group_key_kernel(const unsigned *__restrict__ pd, const int *__restrict__ starts,
+                                                             const int *__restrict__ counts, int HW, int mmax, unsigned ngroups,
+                                                             unsigned *__restrict__ keys, unsigned *__restrict__ vals) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= mmax) return;
+  vals[k] = (unsigned)k;
+  keys[k] = k < counts[1] ? (pd[starts[k]] >> 8) / (unsigned)HW : ngroups;  // unused slots sort behind every camera
+}
+
 // ------------------------------------------------------------------------------ fused forward
 constexpr int kU = 8;
 
@@ -220,18 +235,21 @@ constexpr int kU = 8;
 __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
     const float *__restrict__ depth, int depth_pitch, const float *__restrict__ feat, int feat_pitch,
     const unsigned *__restrict__ pd, const int *__restrict__ starts, const int *__restrict__ lengths,
-    const int *__restrict__ cell_of_interval, const int *__restrict__ counts, int mmax, int cq,
-    int groups, float4 *__restrict__ out) {
+    const int *__restrict__ cell_of_interval, const int *__restrict__ counts, const int *__restrict__ order, int mmax,
+    int cq, int groups, float4 *__restrict__ out) {
   const int m = min(mmax, counts[1]);
   const int lane = threadIdx.x & (kWave - 1);
-  // round-robin block->XCD placement is kept on purpose here: the long intervals (cells next to the ego
-  // vehicle) are contiguous in rank order, and an XCD-chunked mapping puts them all on one XCD
-  // (measured: 0.548 ms chunked vs 0.374 ms round-robin for the batch-4 nuScenes frustum)
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // rank order (order == NULL): round-robin block->XCD placement on purpose -- the long intervals (cells next to the ego
+  // vehicle) are contiguous in rank order and an XCD-chunked mapping puts them all on one XCD (0.548 ms chunked vs
+  // 0.374 ms round-robin, batch-4 nuScenes frustum).  Camera-major order: XCD-chunked, each XCD owns whole cameras and
+  // every camera has its share of long intervals.
+  const long long blk = order ? xcd_chunked_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const long long wave = (blk * blockDim.x + threadIdx.x) >> 6;
   const int g = lane / cq;
   const int q = lane - g * cq;
-  const long long k = wave * groups + g;
-  if (g >= groups || k >= m) return;
+  const long long kp = wave * groups + g;
+  if (g >= groups || kp >= m) return;
+  const long long k = order ? order[kp] : kp;
   const int s = starts[k];
   const int len = lengths[k];
   const unsigned *ppd = pd + s;
@@ -366,7 +384,7 @@ BFHIP_EXPORT int bfhip_bev_plan(const float *frustum, const float *post_trans,
                                 const float *extra_trans, int B, int N, int D, int HW,
                                 const float *origin_host, const float *dx_host,
                                 const int32_t *nx_host, uint32_t *sorted_pd, int32_t *starts,
-                                int32_t *lengths, int32_t *cell_of_interval, int32_t *counts_dev,
+                                int32_t *lengths, int32_t *cell_of_interval, int32_t *interval_order, int32_t *counts_dev,
                                 int32_t *cell_of_point, int32_t *geom_sorted, int64_t *ranks_sorted,
                                 uint8_t *kept, float *geom_xyz, int mmax, void *workspace,
                                 size_t workspace_bytes, void *stream_) {
@@ -416,6 +434,14 @@ BFHIP_EXPORT int bfhip_bev_plan(const float *frustum, const float *post_trans,
                      starts, cell_of_interval, geom_sorted, (long long *)ranks_sorted);
   hipLaunchKernelGGL(plan_lengths_kernel, dim3(ceil_div(mmax, 256)), dim3(256), 0, stream, starts, counts_dev,
                      lengths, mmax);
+  if (interval_order) {  // camera-major order of the intervals (the sort buffers are free again)
+    const unsigned ngroups = (unsigned)(B * N);
+    hipLaunchKernelGGL(plan_group_key_kernel, dim3(ceil_div(mmax, 256)), dim3(256), 0, stream, sorted_pd, starts, counts_dev,
+                       HW, mmax, ngroups, keys_in, vals_in);
+    e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_in, keys_out, vals_in, (unsigned *)interval_order, (size_t)mmax,
+                                  0, key_bits(ngroups), stream);
+    if (e != hipSuccess) { set_error("bev_plan: rocprim sort (order): %s", hipGetErrorString(e)); return BFHIP_E_LAUNCH; }
+  }
   prof_end(&ps);
   return check_launch("bev_plan");
 }
@@ -423,8 +449,8 @@ BFHIP_EXPORT int bfhip_bev_plan(const float *frustum, const float *post_trans,
 BFHIP_EXPORT int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const float *feat,
                                       int feat_pitch, const uint32_t *sorted_pd,
                                       const int32_t *starts, const int32_t *lengths,
-                                      const int32_t *cell_of_interval, const int32_t *counts_dev,
-                                      int mmax, int C, long long out_cells, float *out,
+                                      const int32_t *cell_of_interval, const int32_t *interval_order,
+                                      const int32_t *counts_dev, int mmax, int C, long long out_cells, float *out,
                                       void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(C > 0 && C % 4 == 0 && C / 4 <= kWave, "lift_splat_fwd: C must be a multiple of 4 and <= 256 (C=%d)", C);
@@ -441,7 +467,7 @@ BFHIP_EXPORT int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const
   prof_begin(BFHIP_OP_LIFT_SPLAT_FWD, stream, &ps);
   hipLaunchKernelGGL(lift_splat_fwd_kernel, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
                      depth_pitch, feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
-                     mmax, cq, groups, (float4 *)out);
+                     interval_order, mmax, cq, groups, (float4 *)out);
   prof_end(&ps);
   return check_launch("lift_splat_fwd");
 }

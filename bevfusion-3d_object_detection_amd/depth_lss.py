@@ -14,6 +14,7 @@ happens:
 `bev_pool(x, geom)` / `bev_pool_precomputed(...)` keep the reference's op-boundary semantics for
 callers that hand over a materialised x.
 """
+import os
 from typing import Tuple
 
 import torch
@@ -24,6 +25,9 @@ from .bn2d import bn_act
 from .conv2d import Conv2d
 from .ops import bev_pool
 from .registry import MODELS
+
+
+CAMERA_MAJOR = os.environ.get("BFHIP_LIFT_SPLAT_ORDER", "1") == "1"
 
 
 def _inverse(m):
@@ -60,6 +64,8 @@ class BevPlan:
         self.starts = torch.empty(self.mmax, **i32)
         self.lengths = torch.empty(self.mmax, **i32)
         self.cell_of_interval = torch.empty(self.mmax, **i32)
+        # camera-major processing order of the intervals (lift_splat_fwd locality); BFHIP_LIFT_SPLAT_ORDER=0: rank order
+        self.interval_order = torch.empty(self.mmax, **i32) if CAMERA_MAJOR else None
         self.counts = torch.zeros(2, **i32)
         self.cell_of_point = torch.empty(self.nprime, **i32)
         self.geom_sorted = torch.empty((self.nprime, 4), **i32) if with_reference_outputs else None
@@ -80,7 +86,7 @@ class BevPlan:
             rc = _lib.load().bfhip_bev_plan(
                 *[_lib.ptr(a) for a in args], self.B, self.N, self.D, self.HW, _lib.host_f32(origin), _lib.host_f32(dx),
                 nx_host, _lib.ptr(self.sorted_pd), _lib.ptr(self.starts), _lib.ptr(self.lengths),
-                _lib.ptr(self.cell_of_interval), _lib.ptr(self.counts), _lib.ptr(self.cell_of_point),
+                _lib.ptr(self.cell_of_interval), _lib.ptr(self.interval_order), _lib.ptr(self.counts), _lib.ptr(self.cell_of_point),
                 _lib.ptr(self.geom_sorted), _lib.ptr(self.ranks_sorted), _lib.ptr(self.kept), _lib.ptr(self.geom_xyz),
                 self.mmax, _lib.ptr(self.workspace), self.workspace.numel(), _lib.stream_of(self.sorted_pd))
         _lib.check(rc, "bev_plan")
@@ -102,8 +108,8 @@ class _LiftSplat(torch.autograd.Function):
         with torch.cuda.device(feat.device):
             rc = _lib.load().bfhip_lift_splat_fwd(
                 _lib.ptr(depth), depth.stride(0), _lib.ptr(feat), feat.stride(0), _lib.ptr(plan.sorted_pd),
-                _lib.ptr(plan.starts), _lib.ptr(plan.lengths), _lib.ptr(plan.cell_of_interval), _lib.ptr(plan.counts),
-                plan.mmax, C, plan.out_cells, _lib.ptr(out), _lib.stream_of(feat))
+                _lib.ptr(plan.starts), _lib.ptr(plan.lengths), _lib.ptr(plan.cell_of_interval), _lib.ptr(plan.interval_order),
+                _lib.ptr(plan.counts), plan.mmax, C, plan.out_cells, _lib.ptr(out), _lib.stream_of(feat))
         _lib.check(rc, "lift_splat_fwd")
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan

@@ -150,6 +150,9 @@ int bfhip_voxel_mean(const float *voxels, const int32_t *num_points, int M, int 
  *   sorted_pd        u32[N']  (pixel_index << 8 | depth_bin) of the k-th sorted kept point
  *   starts, lengths  i32[mmax], cell_of_interval i32[mmax] (offset of the cell in out[b][z][x][y])
  *   counts_dev       i32[2] = {n_kept, n_intervals}
+ *   interval_order   i32[mmax] (may be NULL): the intervals in camera-major order -- stably sorted by (sample, camera) of
+ *                    their first member; bfhip_lift_splat_fwd walks them in this order so that every XCD gathers the feature
+ *                    rows of "its" cameras from its own L2 (the cells' sums are unchanged, only their production order)
  *   optional (may be NULL): cell_of_point i32[N'] (out cell of every frustum point or -1; needed by
  *   lift_splat_bwd), geom_sorted i32[N',4] (x,y,z,b), ranks_sorted i64[N'], kept u8[N'],
  *   geom_xyz f32[N',3] (the materialised get_geometry output, for parity tests)
@@ -160,7 +163,7 @@ int bfhip_bev_plan(const float *frustum, const float *post_trans, const float *p
                    const float *extra_trans, int B, int N, int D, int HW,
                    const float *origin_host, const float *dx_host, const int32_t *nx_host,
                    uint32_t *sorted_pd, int32_t *starts, int32_t *lengths,
-                   int32_t *cell_of_interval, int32_t *counts_dev, int32_t *cell_of_point,
+                   int32_t *cell_of_interval, int32_t *interval_order, int32_t *counts_dev, int32_t *cell_of_point,
                    int32_t *geom_sorted, int64_t *ranks_sorted, uint8_t *kept, float *geom_xyz,
                    int mmax, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -174,8 +177,8 @@ int bfhip_bev_plan(const float *frustum, const float *post_trans, const float *p
  * --------------------------------------------------------------------------------------- */
 int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const float *feat, int feat_pitch,
                          const uint32_t *sorted_pd, const int32_t *starts, const int32_t *lengths,
-                         const int32_t *cell_of_interval, const int32_t *counts_dev, int mmax, int C,
-                         long long out_cells, float *out, void *stream);
+                         const int32_t *cell_of_interval, const int32_t *interval_order /* may be NULL: rank order */,
+                         const int32_t *counts_dev, int mmax, int C, long long out_cells, float *out, void *stream);
 int bfhip_lift_splat_bwd(const float *out_grad, const float *depth, int depth_pitch,
                          const float *feat, int feat_pitch, const int32_t *cell_of_point,
                          int num_cams, int D, int HW, int C, float *d_depth, int d_depth_pitch,

@@ -207,3 +207,37 @@ def test_full_size_properties(dev):
                                         plan.starts[:m].contiguous(), 1, 1, 360, 360)
     assert torch.equal(o1, ref)
     assert torch.allclose(o1.double().sum((0, 1, 2, 3)), x.double().sum(0), rtol=1e-6, atol=1e-3)
+
+
+def test_camera_major_interval_order(dev):
+    """bfhip_bev_plan's `interval_order`: a permutation of the intervals, stably sorted by (sample, camera) of the first
+    member -- and lift_splat_fwd produces bit-identical cells whether it walks them in that order or in rank order."""
+    from bevfusion_amd import depth_lss, synthetic
+    from bevfusion_amd.depth_lss import LSSTransform, lift_splat
+    cfg = dict(in_channels=16, out_channels=80, image_size=(64, 176), feature_size=(8, 22), xbound=[-54.0, 54.0, 1.2],
+               ybound=[-54.0, 54.0, 1.2], zbound=[-10.0, 10.0, 20.0], dbound=[1.0, 61.0, 1.0])
+    vt = LSSTransform(**cfg).to(dev)
+    rig = synthetic.camera_rig(batch=2, seed=3, train_aug=True)
+    rig["img_aug_matrix"][..., 0, 0] = rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3], rig["img_aug_matrix"][..., 1, 3] = -8.0, -44.0
+    t = {k: torch.from_numpy(v).to(dev) for k, v in rig.items()}
+    cal = vt._calibration(t["camera_intrinsics"], t["camera2lidar"], t["img_aug_matrix"], t["lidar_aug_matrix"])
+    assert depth_lss.CAMERA_MAJOR
+    plan = vt.make_plan(**cal)
+    n_kept, m = [int(v) for v in plan.counts.cpu()]
+    order = plan.interval_order.cpu().numpy()[:m]
+    assert np.array_equal(np.sort(order), np.arange(m))
+    HW = 8 * 22
+    pd = plan.sorted_pd.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    group = (pd[plan.starts.cpu().numpy()[:m]] >> 8) // HW
+    g_sorted = group[order]
+    assert np.all(np.diff(g_sorted) >= 0)                                   # camera-major
+    assert all(np.all(np.diff(order[g_sorted == g]) > 0) for g in np.unique(group))  # rank order inside a camera (stable)
+    P, D, C = 2 * 6 * HW, vt.D, 80
+    gen = torch.Generator().manual_seed(0)
+    depth = torch.softmax(torch.randn(P, D, generator=gen), 1).to(dev)
+    feat = torch.randn(P, C, generator=gen).to(dev)
+    a = lift_splat(depth, feat, plan)
+    plan.interval_order = None                                              # rank order
+    b = lift_splat(depth, feat, plan)
+    assert torch.equal(a, b)
