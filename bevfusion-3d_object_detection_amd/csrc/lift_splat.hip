@@ -254,6 +254,11 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
   const int len = lengths[k];
   const unsigned *ppd = pd + s;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Measured and dropped (batch-4 nuScenes frustum, same launch): index / row loads software-pipelined one and two groups
+  // ahead of the adds (0.363 vs 0.374 ms), groups of 4 / 16 members (0.39 / 0.53 ms), intervals ordered by descending
+  // length so that a wave's three intervals match (0.347 vs 0.350 ms).  The kernel sits at the per-CU rate of 320-byte row
+  // gathers through the vector L1 (~8 TB/s of useful bytes chip-wide), not on latency, divergence or -- since the
+  // camera-major order -- memory traffic.
   for (int i = 0; i < len; i += kU) {
     const int rem = len - i;
     unsigned e[kU];

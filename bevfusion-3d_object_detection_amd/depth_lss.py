@@ -27,7 +27,12 @@ from .ops import bev_pool
 from .registry import MODELS
 
 
-CAMERA_MAJOR = os.environ.get("BFHIP_LIFT_SPLAT_ORDER", "1") == "1"
+# Camera-major processing order of the BEV intervals in lift_splat_fwd (csrc/lift_splat.hip: plan_group_key_kernel).  It cuts
+# the kernel's memory-side traffic 11x (rocprofv3 FETCH_SIZE 1.1 -> 0.1 GB per batch-4 launch: the gathered feature rows then
+# hit the per-XCD L2) but not its time (0.350 vs 0.374 ms alone, 0.379 vs 0.386 ms inside the step): the kernel is bound by
+# the per-CU rate of 320-byte row gathers through the vector L1, and the extra key sort costs 0.12 ms per plan.  Off by
+# default for that reason; on, it frees ~1 GB of Infinity-Cache / HBM traffic per step for whatever runs beside it.
+CAMERA_MAJOR = os.environ.get("BFHIP_LIFT_SPLAT_ORDER", "0") == "1"
 
 
 def _inverse(m):
@@ -65,7 +70,7 @@ class BevPlan:
         self.lengths = torch.empty(self.mmax, **i32)
         self.cell_of_interval = torch.empty(self.mmax, **i32)
         # camera-major processing order of the intervals (lift_splat_fwd locality); BFHIP_LIFT_SPLAT_ORDER=0: rank order
-        self.interval_order = torch.empty(self.mmax, **i32) if CAMERA_MAJOR else None
+        self.interval_order = torch.empty(self.mmax, **i32) if CAMERA_MAJOR else None  # read at construction (tests patch it)
         self.counts = torch.zeros(2, **i32)
         self.cell_of_point = torch.empty(self.nprime, **i32)
         self.geom_sorted = torch.empty((self.nprime, 4), **i32) if with_reference_outputs else None

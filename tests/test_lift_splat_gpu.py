@@ -209,7 +209,7 @@ def test_full_size_properties(dev):
     assert torch.allclose(o1.double().sum((0, 1, 2, 3)), x.double().sum(0), rtol=1e-6, atol=1e-3)
 
 
-def test_camera_major_interval_order(dev):
+def test_camera_major_interval_order(dev, monkeypatch):
     """bfhip_bev_plan's `interval_order`: a permutation of the intervals, stably sorted by (sample, camera) of the first
     member -- and lift_splat_fwd produces bit-identical cells whether it walks them in that order or in rank order."""
     from bevfusion_amd import depth_lss, synthetic
@@ -222,7 +222,7 @@ def test_camera_major_interval_order(dev):
     rig["img_aug_matrix"][..., 0, 3], rig["img_aug_matrix"][..., 1, 3] = -8.0, -44.0
     t = {k: torch.from_numpy(v).to(dev) for k, v in rig.items()}
     cal = vt._calibration(t["camera_intrinsics"], t["camera2lidar"], t["img_aug_matrix"], t["lidar_aug_matrix"])
-    assert depth_lss.CAMERA_MAJOR
+    monkeypatch.setattr(depth_lss, "CAMERA_MAJOR", True)   # opt-in (BFHIP_LIFT_SPLAT_ORDER=1)
     plan = vt.make_plan(**cal)
     n_kept, m = [int(v) for v in plan.counts.cpu()]
     order = plan.interval_order.cpu().numpy()[:m]
