@@ -63,6 +63,13 @@ __device__ __forceinline__ long long xcd_chunked_block(long long bid, long long 
   return base + slot;
 }
 
+// sparse weight gradient on the bf16 matrix cores (csrc/conv2d.hip: the transposing-LDS-read machinery of the dense conv
+// weight gradient with the rulebook as the gather); called by bfhip_spconv_wgrad for bf16 features
+size_t spconv_wgrad_tr_workspace_bytes(int KV, int Cin, int Cout, int n_rows);
+bool spconv_wgrad_tr_supported(int KV, int Cin, int Cout);
+int spconv_wgrad_tr(const void *in, const void *dout, const int32_t *pairs, int ld, int KV, int n_rows, int Cin, int Cout,
+                    float *dW, void *workspace, size_t workspace_bytes, hipStream_t stream);
+
 }  // namespace bfhip
 
 #define BFHIP_REQUIRE(cond, ...)                \

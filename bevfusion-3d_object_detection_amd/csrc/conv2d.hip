@@ -297,6 +297,67 @@ struct WgradGeom {
 
 __device__ __forceinline__ int tr_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
+// ---- shared by the dense and the sparse weight-gradient kernels: wave tile = 64 rows (wm) x 64 columns (wn) of dW;
+// a 16-lane group reads a 4-pixel x 16-column block with the transposing LDS read
+struct TrAddr { int g[2][2], x[2][2]; };  // [tile 0/1][half], for k-step 0; k-step ks adds ks * 16 rows (swizzle period 16)
+
+__device__ __forceinline__ TrAddr tr_addresses(int lane, int wm, int wn) {
+  const int grp = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3, lh = lane >> 5;
+  TrAddr a;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int r = 8 * lh + 4 * half + tq;  // row inside a 16-pixel k-step
+      const int cg = ((wm * 64 + j * 32) >> 3) + 2 * grp + (tp >> 1);
+      const int cx = ((wn * 64 + j * 32) >> 3) + 2 * grp + (tp >> 1);
+      a.g[j][half] = r * 256 + ((cg ^ tr_swz(r)) << 4) + 8 * (tp & 1);
+      a.x[j][half] = r * 256 + ((cx ^ tr_swz(r)) << 4) + 8 * (tp & 1);
+    }
+  return a;
+}
+
+// one 64-pixel step: acc[i][j] += G^T(tile i) . X(tile j)
+__device__ __forceinline__ void tr_compute_step(const unsigned char *pG, const unsigned char *pX, const TrAddr &ad, f32x16 (&acc)[2][2]) {
+  typedef __attribute__((ext_vector_type(8))) short short8_t;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + ad.g[j][0]));
+      short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + ad.g[j][1]));
+      short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + ad.x[j][0]));
+      short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + ad.x[j][1]));
+      short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      a[j] = __builtin_bit_cast(bf16x8, av);
+      b[j] = __builtin_bit_cast(bf16x8, bv);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// partial slab [Cout][Ktot] (fp32) of one split: rows = co, lanes = k columns (contiguous)
+__device__ __forceinline__ void tr_store_slab(float *out, int Cout, int Ktot, int co0, int q0, int lane, int wm, int wn,
+                                              const f32x16 (&acc)[2][2]) {
+  const int lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = q0 * 8 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < Cout && col < Ktot) out[(size_t)co * Ktot + col] = acc[i][j][r];
+      }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
                                                             float *__restrict__ slab, WgradGeom wg) {
   constexpr int BP = 64, T_BYTES = BP * 256;  // one tile: 64 pixels x 128 columns bf16
@@ -382,21 +443,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // transposing-read addresses: wave tile = 64 co (wm) x 64 k columns (wn); a 16-lane group reads a 4-row x 16-column block
   const int wm = w >> 1, wn = w & 1;
-  const int grp = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3, lh = lane >> 5;
-  // row inside a 16-pixel k-step: 8*lh + 4*half + tq ; column piece: (colbase >> 3) + 2*grp + (tp >> 1) ; + 8*(tp & 1) bytes
-  int addrG[2][2], addrX[2][2];  // [tile 0/1][half], for ks = 0; further k-steps add 16 rows (swizzle repeats every 16 rows)
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int r = 8 * lh + 4 * half + tq;
-      const int cg = ((wm * 64 + j * 32) >> 3) + 2 * grp + (tp >> 1);
-      const int cx = ((wn * 64 + j * 32) >> 3) + 2 * grp + (tp >> 1);
-      addrG[j][half] = r * 256 + ((cg ^ tr_swz(r)) << 4) + 8 * (tp & 1);
-      addrX[j][half] = r * 256 + ((cx ^ tr_swz(r)) << 4) + 8 * (tp & 1);
-    }
+  const TrAddr ad = tr_addresses(lane, wm, wn);
 
   if (nsteps > 0) stage(0);
   for (int t = 0; t < nsteps; ++t) {
@@ -405,42 +453,97 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
     __syncthreads();
     if (t + 1 < nsteps) { advance(); stage(buf ^ 1); }
     const unsigned char *pG = sG + buf * T_BYTES, *pX = sX + buf * T_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 a[2], b[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + addrG[j][0]));
-        short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + addrG[j][1]));
-        short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + addrX[j][0]));
-        short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + addrX[j][1]));
-        typedef __attribute__((ext_vector_type(8))) short short8_t;
-        short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        a[j] = __builtin_bit_cast(bf16x8, av);
-        b[j] = __builtin_bit_cast(bf16x8, bv);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    tr_compute_step(pG, pX, ad, acc);
   }
 
-  // partial slab [split][Cout][Ktot] (fp32): rows = co, lanes = k columns (contiguous)
   const int Ktot = g.nq * 8;
-  float *out = slab + (size_t)split * wg.Cout * Ktot;
+  tr_store_slab(slab + (size_t)split * wg.Cout * Ktot, wg.Cout, Ktot, co0, q0, lane, wm, wn, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ sparse weight gradient
+// dW[co][k][ci] = sum over output rows of dout[row][co] * in[pairs[k][row]][ci]  (SubMConv3d / SparseConv3d, spconv's
+// (out, kD, kH, kW, in) weight layout): the dense kernel above with the rulebook as the gather -- column piece q of a tile is
+// (offset k = q*8 / Cin, channels q*8 % Cin ..+8), its source row is pairs[k][row] (-1: no neighbour -> zero piece).  The
+// pair index of the NEXT 64-row step is loaded while the current step computes, so the index -> row chain costs one
+// round trip per step, not two.  bf16 features in, fp32 accumulate: 16x the matrix rate of the fp32-MFMA kernel in
+// spconv.hip, which stays for fp32 features.
+struct SpWgradGeom {
+  int Cin, Cout, KV, ld, n_rows, nq;  // nq = KV * Cin / 8
+  int splits, tiles_co, tiles_k;
+  int rows_per_split;                  // multiple of 64
+};
+
+__global__ __launch_bounds__(256, 2) void spconv_wgrad_tr_kernel(const bf16_t *__restrict__ in, const bf16_t *__restrict__ dout,
+                                                                 const int *__restrict__ pairs, float *__restrict__ slab,
+                                                                 SpWgradGeom sg) {
+  constexpr int BP = 64, T_BYTES = BP * 256;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char *sG = smem, *sX = smem + 2 * T_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles = sg.tiles_co * sg.tiles_k;
+  const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles * sg.splits);
+  const int split = (int)(lb / tiles), tile = (int)(lb - (long long)split * tiles);
+  const int tco = tile / sg.tiles_k, tk = tile - tco * sg.tiles_k;
+  const int co0 = tco * 128, q0 = tk * 16;
+  const int p_begin = split * sg.rows_per_split;
+  const int p_end = min(p_begin + sg.rows_per_split, sg.n_rows);
+  const int nsteps = p_end > p_begin ? (p_end - p_begin + BP - 1) / BP : 0;
+
+  const int lrow = lane >> 4, lpos = lane & 15;
+  int row[4], pk[4], pci[4], pidx[4];  // this lane's 4 rows, the (offset, channel) of its piece of each, the prefetched pair
+  bool qok[4], cok[4];
+  int gco[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i) {
+    const int r = w * 16 + i * 4 + lrow;
+    const int c = lpos ^ tr_swz(r);
+    const int q = q0 + c;
+    row[i] = p_begin + r;
+    gco[i] = co0 + c * 8;
+    cok[i] = gco[i] < sg.Cout;
+    qok[i] = q < sg.nq;
+    const int k8 = (qok[i] ? q : 0) * 8;
+    pk[i] = k8 / sg.Cin;
+    pci[i] = k8 - pk[i] * sg.Cin;
+    pidx[i] = (qok[i] && row[i] < p_end) ? pairs[(size_t)pk[i] * sg.ld + row[i]] : -1;
+  }
+  auto stage = [&](int buf) {  // rows `row[]`, pairs `pidx[]` (already loaded)
+    unsigned char *dG = sG + buf * T_BYTES + (w * 16) * 256, *dX = sX + buf * T_BYTES + (w * 16) * 256;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = q0 * 8 + wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < wg.Cout && col < Ktot) out[(size_t)co * Ktot + col] = acc[i][j][r];
-      }
+    for (int i = 0; i < 4; ++i) {
+      const bool rok = row[i] < p_end;
+      glds16((rok && cok[i]) ? dout + ((size_t)row[i] * sg.Cout + gco[i]) : (const bf16_t *)g_zero_page, dG + i * 1024);
+      glds16(pidx[i] >= 0 ? in + ((size_t)pidx[i] * sg.Cin + pci[i]) : (const bf16_t *)g_zero_page, dX + i * 1024);
     }
+  };
+  auto advance = [&]() {  // next step's rows and their pair indices (global loads issued here, consumed by the next stage())
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      row[i] += BP;
+      pidx[i] = (qok[i] && row[i] < p_end) ? pairs[(size_t)pk[i] * sg.ld + row[i]] : -1;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int wm = w >> 1, wn = w & 1;
+  const TrAddr ad = tr_addresses(lane, wm, wn);
+
+  if (nsteps > 0) { stage(0); advance(); }
+  for (int t = 0; t < nsteps; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step t in LDS, step t + 1's pair indices in registers
+    __syncthreads();
+    if (t + 1 < nsteps) { stage(buf ^ 1); advance(); }
+    tr_compute_step(sG + buf * T_BYTES, sX + buf * T_BYTES, ad, acc);
+  }
+  const int Ktot = sg.nq * 8;
+  tr_store_slab(slab + (size_t)split * sg.Cout * Ktot, sg.Cout, Ktot, co0, q0, lane, wm, wn, acc);
 }
 
 // dW = sum over splits (fixed order), written as fp32 or bf16
@@ -495,7 +598,54 @@ bool geom_ok(int N, int H, int W, int C, int KH, int KW, int stride, int pad, in
 
 size_t igemm_lds_bytes(int WM, int WN, int stages, int nq) { return (size_t)stages * (WM + WN) * 64 * 128 + (size_t)nq * 4; }
 
+
+// ---- internal entry points for spconv.hip (declared in common.h)
+static void sp_wgrad_plan(int n_rows, int Cout, int Ktot, SpWgradGeom &sg) {
+  sg.tiles_co = ceil_div(Cout, 128);
+  sg.tiles_k = ceil_div(Ktot, 128);
+  const int tiles = sg.tiles_co * sg.tiles_k;
+  const int steps = ceil_div(n_rows, 64);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    cus = 256;
+  }
+  const int slots = 2 * cus;                         // one residency round (see wgrad_plan)
+  int want = tiles >= slots ? 1 : slots / tiles;
+  if (want > steps / 4) want = steps / 4;
+  if (want < 1) want = 1;
+  const int per = ceil_div(steps, want);
+  sg.splits = ceil_div(steps, per);
+  sg.rows_per_split = per * 64;
+}
 }  // namespace
+
+size_t spconv_wgrad_tr_workspace_bytes(int KV, int Cin, int Cout, int n_rows) {
+  SpWgradGeom sg;
+  sp_wgrad_plan(n_rows > 0 ? n_rows : 1, Cout, KV * Cin, sg);
+  return align_up((size_t)sg.splits * Cout * KV * Cin * sizeof(float), 256);
+}
+
+bool spconv_wgrad_tr_supported(int KV, int Cin, int Cout) { return Cin % 8 == 0 && Cout % 8 == 0 && Cin >= 8 && KV >= 1; }
+
+int spconv_wgrad_tr(const void *in, const void *dout, const int32_t *pairs, int ld, int KV, int n_rows, int Cin, int Cout,
+                    float *dW, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  SpWgradGeom sg;
+  sg.Cin = Cin; sg.Cout = Cout; sg.KV = KV; sg.ld = ld; sg.n_rows = n_rows; sg.nq = KV * Cin / 8;
+  sp_wgrad_plan(n_rows, Cout, KV * Cin, sg);
+  if (workspace_bytes < spconv_wgrad_tr_workspace_bytes(KV, Cin, Cout, n_rows)) { set_error("spconv_wgrad: workspace too small"); return BFHIP_E_WORKSPACE; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)spconv_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(spconv_wgrad_tr_kernel, dim3((unsigned)(sg.tiles_co * sg.tiles_k * sg.splits)), dim3(256), (size_t)4 * 64 * 256, stream,
+                     (const bf16_t *)in, (const bf16_t *)dout, pairs, (float *)workspace, sg);
+  const long long total = (long long)Cout * KV * Cin;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(total, 1024)), dim3(256), 0, stream, (const float *)workspace, sg.splits,
+                     total, (void *)dW, 0);
+  return BFHIP_OK;
+}
 }  // namespace bfhip
 
 using namespace bfhip;

@@ -1773,7 +1773,12 @@ BFHIP_EXPORT size_t bfhip_spconv_wgrad_workspace_bytes(int KV, int Cin, int Cout
   size_t uniform = (size_t)S * KV * Cin * Cout * sizeof(float);  // the scalar-load kernel: one slab per row split
   // the streamed 64 x 64 kernel: one slab per (workgroup, tile) incidence + the per-offset pair counts
   size_t streamed = ((size_t)kSkMaxBlocksPerCu * device_cus() + (size_t)kSkRegions * KV * GI * GJ) * 4096 * sizeof(float) + 64 * kCountSlices * sizeof(int);
-  return align_up(uniform > streamed ? uniform : streamed, 256) + 256;
+  size_t need = uniform > streamed ? uniform : streamed;
+  if (spconv_wgrad_tr_supported(KV, Cin, Cout)) {
+    size_t tr = spconv_wgrad_tr_workspace_bytes(KV, Cin, Cout, n_rows);
+    if (tr > need) need = tr;
+  }
+  return align_up(need, 256) + 256;
 }
 
 BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int32_t *pairs, int ld, int KV,
@@ -1795,6 +1800,15 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
   float *partial = (float *)workspace;
   ProfScope ps, ps_op;
   prof_begin(BFHIP_OP_SPCONV_WGRAD, stream, &ps_op);  // the whole op: counts + main + reduce
+  static const int use_tr = getenv("BFHIP_SPCONV_WGRAD_FP32MFMA") ? 0 : 1;
+  if (io_bf16 && use_tr && !perm && spconv_wgrad_tr_supported(KV, Cin, Cout)) {
+    // bf16 features: the bf16-MFMA kernel (16x the matrix rate of the fp32-MFMA kernels below)
+    prof_begin(BFHIP_OP_SPCONV_WGRAD_MAIN, stream, &ps);
+    int rc = spconv_wgrad_tr(in, dout, pairs, ld, KV, n_rows, Cin, Cout, dW, workspace, workspace_bytes, stream);
+    prof_end(&ps);
+    prof_end(&ps_op);
+    return rc != BFHIP_OK ? rc : check_launch("spconv_wgrad");
+  }
   if (vec && KV <= 64) {
     // the row-streamed MFMA kernel: R = 4 | 2 for the narrow square stages (C = 16 | 32), 64 x 64 tiles otherwise
     const int R = (Cin == Cout && Cin == 16) ? 4 : (Cin == Cout && Cin == 32) ? 2 : 1;
