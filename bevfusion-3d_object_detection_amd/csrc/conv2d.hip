@@ -546,14 +546,23 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_tr_kernel(const bf16_t *_
   tr_store_slab(slab + (size_t)split * sg.Cout * Ktot, sg.Cout, Ktot, co0, q0, lane, wm, wn, acc);
 }
 
-// dW = sum over splits (fixed order), written as fp32 or bf16
+// dW = sum over splits (fixed order), written as fp32 or bf16.  The loads of 8 slabs are issued before their adds: one
+// dependent round trip per 8 slabs instead of one per slab (18 slabs of the 128 -> 128 sparse layers: 31 -> ~8 us).
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ slab, int splits, long long total,
                                                                 void *__restrict__ dw, int out_bf16) {
   long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= total) return;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i + 4 <= total) {
-    for (int k = 0; k < splits; ++k) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const float4 *)(slab + (size_t)(k + u) * total + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < splits; ++k) {
       float4 v = *(const float4 *)(slab + (size_t)k * total + i);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
