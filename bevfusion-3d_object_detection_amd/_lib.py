@@ -36,12 +36,13 @@ SIGNATURES = {
                              [_c_vp, _c_int, _c_vp, _c_int, _c_vp]),
     "bfhip_conv_out_shape": (_c_int, [_c_vp] * 6),
     "bfhip_rulebook_subm_workspace_bytes": (_c_sz, [_c_int]),
-    "bfhip_rulebook_subm": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_rulebook_subm": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
+                                     _c_vp]),
     "bfhip_rulebook_sparse_workspace_bytes": (_c_sz, [_c_int] + [_c_vp] * 5),
     "bfhip_rulebook_sparse_count": (_c_int, [_c_vp, _c_int, _c_vp, _c_int] + [_c_vp] * 5 + [_c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_rulebook_sparse_out_indices": (_c_int, [_c_int] + [_c_vp] * 5 + [_c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_rulebook_sparse_fill": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 5 + [_c_int] + [_c_vp] * 4 +
-                                   [_c_vp, _c_sz, _c_vp]),
+                                   [_c_vp] * 4 + [_c_vp, _c_sz] + [_c_vp, _c_sz, _c_vp]),
     "bfhip_spconv_workspace_bytes": (_c_sz, [_c_int] * 3),
     "bfhip_rulebook_sort_rows_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "bfhip_rulebook_sort_rows": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),

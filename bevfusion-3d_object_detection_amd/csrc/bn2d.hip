@@ -14,6 +14,8 @@
 // A thread owns one 16-byte channel vector (8 bf16 / 4 fp32) and strides over rows, so its per-channel coefficients
 // stay in registers; reductions are two-stage in a fixed order (deterministic, no atomics).
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -60,6 +62,14 @@ template <> struct Vec<bf16_t> {
 // A block covers Lb vector columns (Lb*V channels, column tile blockIdx.y) x R row lanes; blockIdx.x is the row slab.
 struct Map { int Lb, R, rpb; };  // vector columns per block, row lanes per block, rows per slab
 
+// Device-coherent accesses for the data that blocks hand to one another inside a launch (finish_in_last_block): agent-scope
+// relaxed atomics go to the coherence point themselves (sc1 loads / write-through stores), so no cache-wide release / acquire
+// is needed.  (__threadfence() here = an L2 write-back + invalidate per block: measured +16 ms on the 36 ms training step.)
+template <typename T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all of this thread's stores have been acknowledged (s_waitcnt only)
+__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
 // block-level combine of per-thread (s0[V], s1[V]) over the R row lanes -> partial[blk][2][C]
 template <int V>
 __device__ __forceinline__ void combine_rows(const float *s0, const float *s1, int Lb, int R, int C,
@@ -74,14 +84,137 @@ __device__ __forceinline__ void combine_rows(const float *s0, const float *s1, i
   for (int cl = t; cl < Lb * V && c0 + cl < C; cl += 256) {
     float a = 0.f, b = 0.f;
     for (int rl = 0; rl < R; ++rl) { a += m0[rl * Lb * V + cl]; b += m1[rl * Lb * V + cl]; }
-    partial[((size_t)blockIdx.x * 2 + 0) * C + c0 + cl] = a;
-    partial[((size_t)blockIdx.x * 2 + 1) * C + c0 + cl] = b;
+    st_agent(&partial[((size_t)blockIdx.x * 2 + 0) * C + c0 + cl], a);
+    st_agent(&partial[((size_t)blockIdx.x * 2 + 1) * C + c0 + cl], b);
   }
 }
 
+// ---- finalize inside the reduction launch -------------------------------------------------------------------------------
+// The per-channel finalisation (mean / invstd / affine coefficients, or dgamma / dbeta / dx coefficients) used to be a third
+// launch between the reduction and the elementwise pass: ~5 us of kernel plus a launch gap, 208 times per training step.
+// It now runs in the LAST-ARRIVING block of the reduction launch, as a two-level tree so that no block ever reads more than
+// 32 partial rows: the slabs of a column tile form groups of 32; the last block of a group to arrive adds the group's partial
+// rows (fp64, slab order) into gp[group]; the last group to finish adds the <= 32 group rows (group order) and finalises.
+// Sums are therefore in a fixed order whatever the arrival order (deterministic).  Arrival counters live in a small
+// zero-initialised, self-resetting buffer owned by the library, one per stream (kernels of one stream run in order).
+constexpr int kGroup = 32;
+struct Tree {
+  int *cnt;    // [column tile][1 + ng] arrival counters (all zero between launches)
+  double *gp;  // [ng][2][C] group sums
+  int nblk, ng;
+};
+
+template <typename Fin>
+__device__ __forceinline__ void finish_in_last_block(const float *__restrict__ partial, Tree tr, int C, int c0, int ncl,
+                                                     Fin fin) {
+  __shared__ int s_flag;
+  if (!tr.cnt) return;  // finalisation as a separate launch (BFHIP_BN2D_FOLD=0, A/B)
+  const int t = threadIdx.x;
+  const int g = blockIdx.x / kGroup;
+  const int k0 = g * kGroup;
+  const int gsize = tr.nblk - k0 < kGroup ? tr.nblk - k0 : kGroup;
+  int *cnt = tr.cnt + (size_t)blockIdx.y * (1 + tr.ng);
+  stores_done();  // this block's partial row has reached the coherence point before its arrival is counted
+  __syncthreads();
+  if (t == 0) s_flag = __hip_atomic_fetch_add(&cnt[1 + g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+  __syncthreads();
+  if (!s_flag) return;
+  const int c = c0 + t;
+  const bool own = t < ncl && c < C;
+  if (own) {
+    double a = 0.0, b = 0.0;
+    int k = 0;
+    for (; k + 8 <= gsize; k += 8) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v0[u] = ld_agent(&partial[((size_t)(k0 + k + u) * 2 + 0) * C + c]);
+        v1[u] = ld_agent(&partial[((size_t)(k0 + k + u) * 2 + 1) * C + c]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += (double)v0[u]; b += (double)v1[u]; }
+    }
+    for (; k < gsize; ++k) {
+      a += (double)ld_agent(&partial[((size_t)(k0 + k) * 2 + 0) * C + c]);
+      b += (double)ld_agent(&partial[((size_t)(k0 + k) * 2 + 1) * C + c]);
+    }
+    st_agent(&tr.gp[((size_t)g * 2 + 0) * C + c], a);
+    st_agent(&tr.gp[((size_t)g * 2 + 1) * C + c], b);
+  }
+  stores_done();
+  __syncthreads();
+  if (t == 0) {
+    st_agent(&cnt[1 + g], 0);  // every block of the group has arrived: leave the counter as it was found
+    s_flag = __hip_atomic_fetch_add(&cnt[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tr.ng - 1;
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  if (t == 0) st_agent(&cnt[0], 0);
+  if (own) {
+    double s = 0.0, s2 = 0.0;
+    for (int g2 = 0; g2 < tr.ng; ++g2) {
+      s += ld_agent(&tr.gp[((size_t)g2 * 2 + 0) * C + c]);
+      s2 += ld_agent(&tr.gp[((size_t)g2 * 2 + 1) * C + c]);
+    }
+    fin(c, s, s2);
+  }
+}
+
+// stats[0..C) mean, [C..2C) invstd, [2C..3C) a = gamma*invstd, [3C..4C) b = beta - mean*a
+// m_dev (optional): number of ACTIVE rows, on the device; the rows beyond it are exact zeros (feature matrices of the sparse
+// encoder in static capacity mode), so only the divisor changes
+struct FwdFin {
+  long long M;
+  const int *m_dev;
+  int C;
+  float eps, momentum;
+  const float *gamma, *beta;
+  float *stats, *running_mean, *running_var;
+  __device__ __forceinline__ void operator()(int c, double s, double s2) const {
+    long long Mv = M;
+    if (m_dev) { long long mv = *m_dev; Mv = mv < 1 ? 1 : (mv < M ? mv : M); }
+    double mean = s / (double)Mv;
+    double var = s2 / (double)Mv - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float a = gamma[c] * invstd;
+    stats[c] = (float)mean;
+    stats[C + c] = invstd;
+    stats[2 * C + c] = a;
+    stats[3 * C + c] = beta[c] - (float)mean * a;
+    if (running_mean) {
+      double unbiased = Mv > 1 ? var * (double)Mv / (double)(Mv - 1) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+};
+
+// dgb[0..C) dgamma, [C..2C) dbeta; coef[0..C) c1, [C..2C) c2, [2C..3C) c3 with dx = c1*g + c2*x + c3
+struct BwdFin {
+  long long M;
+  const int *m_dev;
+  int C;
+  const float *stats;
+  float *dgb, *coef;
+  __device__ __forceinline__ void operator()(int c, double s, double s2) const {
+    long long Mv = M;
+    if (m_dev) { long long mv = *m_dev; Mv = mv < 1 ? 1 : (mv < M ? mv : M); }
+    const float mean = stats[c], invstd = stats[C + c], a = stats[2 * C + c];
+    const float dbeta = (float)s, dgamma = (float)(s2 * (double)invstd);
+    dgb[c] = dgamma;
+    dgb[C + c] = dbeta;
+    const float invM = (float)(1.0 / (double)Mv);
+    const float c2 = -a * invstd * dgamma * invM;
+    coef[c] = a;
+    coef[C + c] = c2;
+    coef[2 * C + c] = -a * dbeta * invM - c2 * mean;
+  }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn2d_stats_kernel(const T *__restrict__ x, long long M, int C, Map mp,
-                                                         float *__restrict__ partial) {
+                                                         float *__restrict__ partial, Tree tr, FwdFin fin) {
   constexpr int V = Vec<T>::V;
   __shared__ float sm[2 * 256 * V];
   const int t = threadIdx.x, cv = blockIdx.y * mp.Lb + t % mp.Lb, rl = t / mp.Lb;
@@ -110,6 +243,7 @@ __global__ __launch_bounds__(256) void bn2d_stats_kernel(const T *__restrict__ x
     }
   }
   combine_rows<V>(s0, s1, mp.Lb, mp.R, C, partial, sm);
+  finish_in_last_block(partial, tr, C, blockIdx.y * mp.Lb * V, mp.Lb * V, fin);
 }
 
 // 8 channels per block x 32 slab lanes; every lane issues its (<= 32) loads in independent groups of 4, then a fixed-order
@@ -144,35 +278,14 @@ __device__ __forceinline__ void reduce_partials8(const float *__restrict__ parti
     for (int k = 0; k < 32; ++k) { s += sm[0][k * 8 + threadIdx.x]; s2 += sm[1][k * 8 + threadIdx.x]; }
 }
 
-// stats[0..C) mean, [C..2C) invstd, [2C..3C) a = gamma*invstd, [3C..4C) b = beta - mean*a
-// m_dev (optional): number of ACTIVE rows, on the device; the rows beyond it are exact zeros (feature matrices of the sparse
-// encoder in static capacity mode), so only the divisor changes
-__global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float *__restrict__ partial, int nblk, long long M,
-                                                            const int *__restrict__ m_dev, int C, float eps, float momentum,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta,
-                                                            float *__restrict__ stats,
-                                                            float *__restrict__ running_mean,
-                                                            float *__restrict__ running_var) {
+// finalisation as its own launch: for partial sums that come from somewhere else (the conv epilogue, bfhip_bn2d_fwd_partials)
+template <typename Fin>
+__global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float *__restrict__ partial, int nblk, Fin fin) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s, s2;
-  reduce_partials8(partial, nblk, C, c, c < C, s, s2);
-  if (threadIdx.x >= 8 || c >= C) return;
-  if (m_dev) { long long mv = *m_dev; M = mv < 1 ? 1 : (mv < M ? mv : M); }
-  double mean = s / (double)M;
-  double var = s2 / (double)M - mean * mean;
-  if (var < 0.0) var = 0.0;
-  float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  float a = gamma[c] * invstd;
-  stats[c] = (float)mean;
-  stats[C + c] = invstd;
-  stats[2 * C + c] = a;
-  stats[3 * C + c] = beta[c] - (float)mean * a;
-  if (running_mean) {
-    double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
+  reduce_partials8(partial, nblk, fin.C, c, c < fin.C, s, s2);
+  if (threadIdx.x >= 8 || c >= fin.C) return;
+  fin(c, s, s2);
 }
 
 template <typename T, bool RES, bool RELU>
@@ -237,7 +350,7 @@ template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T *__restrict__ dy, const T *__restrict__ x,
                                                               const T *__restrict__ y,
                                                               const float *__restrict__ stats, long long M, int C,
-                                                              Map mp, float *__restrict__ partial) {
+                                                              Map mp, float *__restrict__ partial, Tree tr, BwdFin fin) {
   constexpr int V = Vec<T>::V;
   __shared__ float sm[2 * 256 * V];
   const int t = threadIdx.x, cv = blockIdx.y * mp.Lb + t % mp.Lb, rl = t / mp.Lb;
@@ -284,27 +397,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T *__restric
     }
   }
   combine_rows<V>(s0, s1, mp.Lb, mp.R, C, partial, sm);
-}
-
-// dgb[0..C) dgamma, [C..2C) dbeta; coef[0..C) c1, [C..2C) c2, [2C..3C) c3 with dx = c1*g + c2*x + c3
-__global__ __launch_bounds__(256) void bn2d_bwd_finalize_kernel(const float *__restrict__ partial, int nblk,
-                                                                long long M, const int *__restrict__ m_dev, int C,
-                                                                const float *__restrict__ stats,
-                                                                float *__restrict__ dgb, float *__restrict__ coef) {
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
-  double s, s2;
-  reduce_partials8(partial, nblk, C, c, c < C, s, s2);
-  if (threadIdx.x >= 8 || c >= C) return;
-  if (m_dev) { long long mv = *m_dev; M = mv < 1 ? 1 : (mv < M ? mv : M); }
-  const float mean = stats[c], invstd = stats[C + c], a = stats[2 * C + c];
-  const float dbeta = (float)s, dgamma = (float)(s2 * (double)invstd);
-  dgb[c] = dgamma;
-  dgb[C + c] = dbeta;
-  const float invM = (float)(1.0 / (double)M);
-  const float c2 = -a * invstd * dgamma * invM;
-  coef[c] = a;
-  coef[C + c] = c2;
-  coef[2 * C + c] = -a * dbeta * invM - c2 * mean;
+  finish_in_last_block(partial, tr, C, blockIdx.y * mp.Lb * V, mp.Lb * V, fin);
 }
 
 template <typename T, int MASK, bool DRES>
@@ -403,19 +496,75 @@ int run_fwd(const void *x, const void *res, const float *stats, long long M, int
 }
 
 template <typename T, int MASK>
-void run_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma, long long M, int C,
-             Map mp, dim3 grid, float *partial, float *coef, float *dgb, void *dx, void *dres, const int *m_dev, hipStream_t s) {
-  const int nblk = (int)grid.x;
+void run_bwd(const void *dy, const void *x, const void *y, const float *stats, long long M, int C, Map mp, dim3 grid,
+             float *partial, float *coef, Tree tr, BwdFin fin, void *dx, void *dres, hipStream_t s) {
   hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<T, MASK>), grid, dim3(256), 0, s, (const T *)dy, (const T *)x,
-                     (const T *)y, stats, M, C, mp, partial);
-  hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, m_dev, C, stats, dgb,
-                     coef);
+                     (const T *)y, stats, M, C, mp, partial, tr, fin);
+  if (!tr.cnt) hipLaunchKernelGGL(bn2d_finalize_kernel<BwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, tr.nblk, fin);
   if (dres)
     hipLaunchKernelGGL((bn2d_bwd_apply_kernel<T, MASK, true>), grid, dim3(256), 0, s, (const T *)dy, (const T *)x,
                        (const T *)y, stats, coef, M, C, mp, (T *)dx, (T *)dres);
   else
     hipLaunchKernelGGL((bn2d_bwd_apply_kernel<T, MASK, false>), grid, dim3(256), 0, s, (const T *)dy,
                        (const T *)x, (const T *)y, stats, coef, M, C, mp, (T *)dx, (T *)nullptr);
+}
+
+// Arrival counters of finish_in_last_block: one zero-initialised slab per (device, stream), handed out from a pool that is
+// allocated on the first call on a device (a warm-up step, never inside a stream capture), so that a stream first seen during
+// a capture still gets its slab without an allocation.  Kernels of one stream run in order and leave their slab zeroed.
+constexpr int kSlabInts = 16384;  // >= CT * (1 + ng) = 256 * 33
+constexpr int kSlabs = 32;
+
+inline bool fold_enabled() {
+  static const bool on = [] { const char *e = getenv("BFHIP_BN2D_FOLD"); return e && e[0] == '1'; }();
+  return on;
+}
+
+int *arrival_counters(hipStream_t stream) {
+  static std::mutex mu;
+  static std::map<int, int *> pool;                         // device -> kSlabs slabs
+  static std::map<std::pair<int, hipStream_t>, int> slot;   // (device, stream) -> slab index
+  static std::map<int, int> used;                           // device -> slabs handed out
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = pool.find(dev);
+  if (it == pool.end()) {
+    int *p = nullptr;
+    const size_t bytes = (size_t)kSlabs * kSlabInts * sizeof(int);
+    if (hipMalloc((void **)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+      set_error("bn2d: cannot allocate the arrival counters (first call on a device must be outside a stream capture)");
+      return nullptr;
+    }
+    it = pool.emplace(dev, p).first;
+  }
+  auto key = std::make_pair(dev, stream);
+  auto st = slot.find(key);
+  if (st == slot.end()) {
+    // more streams than slabs: share the last slab round-robin is NOT safe, so refuse
+    if (used[dev] >= kSlabs) { set_error("bn2d: more than %d streams per device in use", kSlabs); return nullptr; }
+    st = slot.emplace(key, used[dev]++).first;
+  }
+  return it->second + (size_t)st->second * kSlabInts;
+}
+
+struct Plan {
+  Map mp;
+  dim3 grid;
+  int nblk, ng;
+  float *partial, *coef;
+  double *gp;
+};
+
+inline size_t plan_bytes(long long M, int C, int dtype, Plan *pl, void *workspace) {
+  pl->mp = make_map(M, C, dtype, &pl->grid);
+  pl->nblk = (int)pl->grid.x;
+  pl->ng = (pl->nblk + kGroup - 1) / kGroup;
+  size_t off = 0;
+  pl->partial = (float *)((char *)workspace + off); off += align_up((size_t)pl->nblk * 2 * C * sizeof(float), 256);
+  pl->coef = (float *)((char *)workspace + off); off += align_up((size_t)3 * C * sizeof(float), 256);
+  pl->gp = (double *)((char *)workspace + off); off += align_up((size_t)pl->ng * 2 * C * sizeof(double), 256);
+  return off;
 }
 
 }  // namespace
@@ -429,9 +578,8 @@ BFHIP_EXPORT int bfhip_bn2d_supported(long long M, int C, int dtype) {
 
 BFHIP_EXPORT size_t bfhip_bn2d_workspace_bytes(long long M, int C, int dtype) {
   if (!bfhip_bn2d_supported(M, C, dtype)) return 0;
-  dim3 grid;
-  make_map(M, C, dtype, &grid);
-  return align_up((size_t)grid.x * 2 * C * sizeof(float), 256) + align_up((size_t)3 * C * sizeof(float), 256);
+  Plan pl;
+  return plan_bytes(M, C, dtype, &pl, nullptr);
 }
 
 BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float *gamma, const float *beta,
@@ -444,18 +592,20 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
   BFHIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0,
                 "bn2d_fwd: tensors must be 16-byte aligned");
   if (!workspace || workspace_bytes < bfhip_bn2d_workspace_bytes(M, C, dtype)) { set_error("bn2d_fwd: workspace too small"); return BFHIP_E_WORKSPACE; }
-  dim3 grid;
-  Map mp = make_map(M, C, dtype, &grid);
-  const int nblk = (int)grid.x;
-  float *partial = (float *)workspace;
+  Plan pl;
+  plan_bytes(M, C, dtype, &pl, workspace);
+  int *cnt = fold_enabled() ? arrival_counters(s) : nullptr;
+  if (!cnt && fold_enabled()) return BFHIP_E_LAUNCH;
+  BFHIP_REQUIRE((long long)pl.grid.y * (1 + pl.ng) <= kSlabInts, "bn2d_fwd: too many column tiles");
+  Tree tr{cnt, pl.gp, pl.nblk, pl.ng};
+  FwdFin fin{M, m_dev, C, eps, momentum, gamma, beta, stats, running_mean, running_var};
   if (dtype == 1)
-    hipLaunchKernelGGL(bn2d_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)x, M, C, mp, partial);
+    hipLaunchKernelGGL(bn2d_stats_kernel<bf16_t>, pl.grid, dim3(256), 0, s, (const bf16_t *)x, M, C, pl.mp, pl.partial, tr, fin);
   else
-    hipLaunchKernelGGL(bn2d_stats_kernel<float>, grid, dim3(256), 0, s, (const float *)x, M, C, mp, partial);
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, m_dev, C, eps, momentum,
-                     gamma, beta, stats, running_mean, running_var);
-  if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
-  else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
+    hipLaunchKernelGGL(bn2d_stats_kernel<float>, pl.grid, dim3(256), 0, s, (const float *)x, M, C, pl.mp, pl.partial, tr, fin);
+  if (!cnt) hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, pl.partial, pl.nblk, fin);
+  if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, pl.mp, pl.grid, relu, y, s);
+  else run_fwd<float>(x, residual, stats, M, C, pl.mp, pl.grid, relu, y, s);
   return check_launch("bn2d_fwd");
 }
 
@@ -470,8 +620,8 @@ BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, co
                 "bn2d_fwd_partials: tensors must be 16-byte aligned");
   dim3 grid;
   Map mp = make_map(M, C, dtype, &grid);
-  hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, M, m_dev, C, eps, momentum,
-                     gamma, beta, stats, running_mean, running_var);
+  FwdFin fin{M, m_dev, C, eps, momentum, gamma, beta, stats, running_mean, running_var};
+  hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, fin);
   if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
   else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
   return check_launch("bn2d_fwd_partials");
@@ -486,21 +636,25 @@ BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, co
   BFHIP_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
                     ((uintptr_t)y % 16) == 0 && ((uintptr_t)dres % 16) == 0, "bn2d_bwd: tensors must be 16-byte aligned");
   if (!workspace || workspace_bytes < bfhip_bn2d_workspace_bytes(M, C, dtype)) { set_error("bn2d_bwd: workspace too small"); return BFHIP_E_WORKSPACE; }
-  dim3 grid;
-  Map mp = make_map(M, C, dtype, &grid);
-  const int nblk = (int)grid.x;
-  float *partial = (float *)workspace;
-  float *coef = (float *)((char *)workspace + align_up((size_t)nblk * 2 * C * sizeof(float), 256));
+  Plan pl;
+  plan_bytes(M, C, dtype, &pl, workspace);
+  int *cnt = fold_enabled() ? arrival_counters(s) : nullptr;
+  if (!cnt && fold_enabled()) return BFHIP_E_LAUNCH;
+  BFHIP_REQUIRE((long long)pl.grid.y * (1 + pl.ng) <= kSlabInts, "bn2d_bwd: too many column tiles");
+  Tree tr{cnt, pl.gp, pl.nblk, pl.ng};
+  BwdFin fin{M, m_dev, C, stats, dgb, pl.coef};
   // ReLU mask: from the saved output when one is given (residual layers), otherwise recomputed from x
   const int mask = !relu ? 0 : (y ? 2 : 1);
+#define BFHIP_BN2D_BWD(T, MASK) run_bwd<T, MASK>(dy, x, y, stats, M, C, pl.mp, pl.grid, pl.partial, pl.coef, tr, fin, dx, dres, s)
   if (dtype == 1) {
-    if (mask == 0) run_bwd<bf16_t, 0>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
-    else if (mask == 1) run_bwd<bf16_t, 1>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
-    else run_bwd<bf16_t, 2>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
+    if (mask == 0) BFHIP_BN2D_BWD(bf16_t, 0);
+    else if (mask == 1) BFHIP_BN2D_BWD(bf16_t, 1);
+    else BFHIP_BN2D_BWD(bf16_t, 2);
   } else {
-    if (mask == 0) run_bwd<float, 0>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
-    else if (mask == 1) run_bwd<float, 1>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
-    else run_bwd<float, 2>(dy, x, y, stats, gamma, M, C, mp, grid, partial, coef, dgb, dx, dres, m_dev, s);
+    if (mask == 0) BFHIP_BN2D_BWD(float, 0);
+    else if (mask == 1) BFHIP_BN2D_BWD(float, 1);
+    else BFHIP_BN2D_BWD(float, 2);
   }
+#undef BFHIP_BN2D_BWD
   return check_launch("bn2d_bwd");
 }

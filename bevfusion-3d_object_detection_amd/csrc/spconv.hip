@@ -113,6 +113,69 @@ __global__ __launch_bounds__(256) void subm_pairs_kernel(const int4 *__restrict_
   }
 }
 
+// Row-block form of the SubM rulebook: a workgroup is 64 rows x (k0*k1) offset columns, each thread probes the k2 offsets of
+// its (i, j) column for its row.  Every pair_fwd entry is written exactly once (holes included: no pre-fill of the table),
+// the k-th plane's 64 entries of a wave are one coalesced store, and the row's offset mask is assembled in LDS, so the row
+// mask, the identity permutation and the (region, mask) sort key leave in the same launch (what row_mask_kernel did in a
+// second pass over the table).  No atomics on global memory: the pair count is the popcount of the masks.
+template <int K2>
+__global__ __launch_bounds__(1024) void subm_pairs_rows_kernel(const int4 *__restrict__ indices, int N, ConvGeom G,
+                                                               const int2 *__restrict__ table, unsigned tmask,
+                                                               int *__restrict__ pair_fwd, unsigned *__restrict__ row_mask,
+                                                               unsigned *__restrict__ iota, unsigned *__restrict__ keys,
+                                                               int regions, int *__restrict__ n_pairs) {
+  __shared__ unsigned smask[64];
+  const int lane = threadIdx.x, ty = threadIdx.y;
+  const int n = blockIdx.x * 64 + lane;
+  if (ty == 0) smask[lane] = 0u;
+  __syncthreads();
+  const int k2 = K2 ? K2 : G.k2;
+  const int i = ty / G.k1, j = ty - i * G.k1;
+  int4 c = n < N ? indices[n] : make_int4(-1, 0, 0, 0);
+  const int x = c.y + (i - G.k0 / 2) * G.d0, y = c.z + (j - G.k1 / 2) * G.d1;
+  const bool xy_ok = c.x >= 0 && x >= 0 && x < G.in0 && y >= 0 && y < G.in1;
+  const bool centre_col = x == c.y && y == c.z;
+  const int base = ((c.x * G.in0 + x) * G.in1 + y) * G.in2;
+  unsigned bits = 0u;
+#pragma unroll
+  for (int l = 0; l < k2; ++l) {
+    const int k = ty * k2 + l;
+    const int z = c.w + (l - k2 / 2) * G.d2;
+    int found = -1;
+    if (xy_ok && z >= 0 && z < G.in2) {
+      if (centre_col && z == c.w) {
+        found = n;
+      } else {
+        const int key = base + z;
+        unsigned s = hash32((unsigned)key) & tmask;
+        for (unsigned probe = 0; probe <= tmask; ++probe) {
+          int2 e = table[s];
+          if (e.x == key) { found = e.y; break; }
+          if (e.x == -1) break;
+          s = (s + 1) & tmask;
+        }
+      }
+    }
+    if (n < N) pair_fwd[(size_t)k * N + n] = found;
+    bits |= (found >= 0 ? 1u : 0u) << (k & 31);
+  }
+  if (bits) atomicOr(&smask[lane], bits);
+  __syncthreads();
+  if (ty == 0) {
+    const unsigned m = smask[lane];
+    if (n < N) {
+      if (row_mask) row_mask[n] = m;
+      if (iota) iota[n] = (unsigned)n;
+      if (keys) keys[n] = (regions > 1 ? (unsigned)(((long long)n * regions) / N) << G.KV : 0u) | m;
+    }
+    if (n_pairs) {
+      int cnt = __popc(m);
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+      if (lane == 0 && cnt) atomicAdd(&n_pairs[blockIdx.x & 63], cnt);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- strided rulebook
 __device__ __forceinline__ bool out_coord(const ConvGeom &G, int4 c, int k, int &ox, int &oy, int &oz) {
   int l = k % G.k2, j = (k / G.k2) % G.k1, i = k / (G.k2 * G.k1);
@@ -250,6 +313,62 @@ __global__ __launch_bounds__(256) void sparse_pairs_kernel(const int4 *__restric
   }
   unsigned long long bal = __ballot(ok);
   if (n_pairs && (threadIdx.x & 63) == 0 && bal) atomicAdd(&n_pairs[(blockIdx.x * 4 + (threadIdx.x >> 6) + k) & 63], __popcll(bal));
+}
+
+// Row-block form of sparse_pairs_kernel (same tables): workgroup = 64 input rows x (k0*k1) offset columns, a thread walks the
+// k2 offsets of its column.  pair_bwd planes are written coalesced, the input rows' offset masks (the backward table's row
+// masks) are assembled in LDS and leave with the identity permutation and the sort key; no global atomics.
+template <int K2>
+__global__ __launch_bounds__(1024) void sparse_pairs_rows_kernel(const int4 *__restrict__ indices, int N, ConvGeom G,
+                                                                 const unsigned *__restrict__ bitmap,
+                                                                 const int *__restrict__ word_prefix, int ld_out,
+                                                                 int *__restrict__ pair_fwd, int *__restrict__ pair_bwd,
+                                                                 unsigned *__restrict__ row_mask, unsigned *__restrict__ iota,
+                                                                 unsigned *__restrict__ keys, int regions,
+                                                                 int *__restrict__ n_pairs) {
+  __shared__ unsigned smask[64];
+  const int lane = threadIdx.x, ty = threadIdx.y;
+  const int n = blockIdx.x * 64 + lane;
+  if (ty == 0) smask[lane] = 0u;
+  __syncthreads();
+  const int k2 = K2 ? K2 : G.k2;
+  const int i = ty / G.k1, j = ty - i * G.k1;
+  int4 c = n < N ? indices[n] : make_int4(-1, 0, 0, 0);
+  int ox = c.y + G.p0 - i * G.d0, oy = c.z + G.p1 - j * G.d1;
+  bool xy_ok = c.x >= 0 && ox >= 0 && oy >= 0 && (ox % G.s0) == 0 && (oy % G.s1) == 0;
+  ox /= G.s0; oy /= G.s1;
+  xy_ok = xy_ok && ox < G.out0 && oy < G.out1;
+  const long long base = (((long long)c.x * G.out0 + ox) * G.out1 + oy) * G.out2;
+  unsigned bits = 0u;
+#pragma unroll
+  for (int l = 0; l < k2; ++l) {
+    const int k = ty * k2 + l;
+    int oz = c.w + G.p2 - l * G.d2;
+    int o = -1;
+    if (xy_ok && oz >= 0 && (oz % G.s2) == 0 && oz / G.s2 < G.out2) {
+      const long long cell = base + oz / G.s2;
+      const unsigned wbits = bitmap[cell >> 5];
+      o = word_prefix[cell >> 5] + __popc(wbits & ((1u << (cell & 31)) - 1u));
+      if (o < ld_out) pair_fwd[(size_t)k * ld_out + o] = n;
+      bits |= 1u << (k & 31);
+    }
+    if (n < N) pair_bwd[(size_t)k * N + n] = o;
+  }
+  if (bits) atomicOr(&smask[lane], bits);
+  __syncthreads();
+  if (ty == 0) {
+    const unsigned m = smask[lane];
+    if (n < N) {
+      if (row_mask) row_mask[n] = m;
+      if (iota) iota[n] = (unsigned)n;
+      if (keys) keys[n] = (regions > 1 ? (unsigned)(((long long)n * regions) / N) << G.KV : 0u) | m;
+    }
+    if (n_pairs) {
+      int cnt = __popc(m);
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+      if (lane == 0 && cnt) atomicAdd(&n_pairs[blockIdx.x & 63], cnt);
+    }
+  }
 }
 
 // -------------------------------------------------------------------------------- row masks
@@ -1448,21 +1567,69 @@ BFHIP_EXPORT int bfhip_conv_out_shape(const int *in_shape, const int *ksize, con
   return BFHIP_OK;
 }
 
+// Row masks + mask-sorted row permutation of a pair table (for tile-level offset skipping).
+// rocPRIM sorts fewer than 2^20 items with a block sort + log2(n / block) merge passes (10 launches of ~5 us for the 10^5 rows
+// of an encoder level).  Forcing its Onesweep radix path (merge limit 0) was measured and is slower here: the 12 sorts of a
+// LiDAR pass took 1.29 ms instead of 0.52 ms (tools/sparse_micro.py), so the default configuration stays.
+using RowSortConfig = rocprim::default_config;
+
+static inline size_t sort32_bytes(int n, int bits) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs<RowSortConfig, unsigned *, unsigned *, unsigned *, unsigned *>(
+      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, bits, 0);
+  return bytes;
+}
+
+BFHIP_EXPORT size_t bfhip_rulebook_sort_rows_workspace_bytes(int n_rows, int KV) {
+  (void)KV;
+  if (n_rows <= 0) return 256;
+  return 3 * align_up((size_t)n_rows * 4, 256) + align_up(sort32_bytes(n_rows, 32), 256) + 256;
+}
+
+namespace {
+// Sort key = (region of the row, mask): rows come in voxel order, so a region is a slab of space.  With the gather-GEMM's
+// XCD-chunked block order each XCD then walks one region and the neighbour rows it gathers stay in its own 4 MiB L2
+// (forward gather-GEMM of the encoder's layers 15-25 % faster than with a pure mask sort, tools/gemm_micro.py; 16 or
+// 32 regions measured no better).  Tiles still share their offsets inside a region.
+inline int sort_regions(int KV) { return KV + 3 <= 32 ? 8 : 1; }
+inline int sort_bits(int KV) { return KV + (KV + 3 <= 32 ? 3 : 0); }
+
+struct SortScratch {
+  unsigned *iota, *keys_out, *keys;
+  char *tmp;
+  size_t tmp_bytes;
+  SortScratch(void *workspace, size_t bytes, int n_rows) {
+    Workspace ws(workspace, bytes);
+    iota = ws.take<unsigned>(n_rows);
+    keys_out = ws.take<unsigned>(n_rows);
+    keys = ws.take<unsigned>(n_rows);
+    tmp_bytes = sort32_bytes(n_rows, 32);
+    tmp = ws.take<char>(tmp_bytes);
+  }
+  hipError_t sort(int n_rows, int KV, int32_t *perm, hipStream_t stream) {
+    return rocprim::radix_sort_pairs<RowSortConfig>(tmp, tmp_bytes, keys, keys_out, iota, (unsigned *)perm, (size_t)n_rows, 0, sort_bits(KV), stream);
+  }
+};
+}  // namespace
+
+// SubM rulebook.  row_mask / perm (optional, KV <= 32): the offset masks of the rows and their (region, mask)-sorted order, as
+// bfhip_rulebook_sort_rows(pair_fwd) would give them, produced by the same launch that fills the table.
 BFHIP_EXPORT size_t bfhip_rulebook_subm_workspace_bytes(int N) {
-  return align_up((size_t)table_cap(N > 0 ? N : 1) * sizeof(int2), 256) + 256;
+  return align_up((size_t)table_cap(N > 0 ? N : 1) * sizeof(int2), 256) + bfhip_rulebook_sort_rows_workspace_bytes(N, 27) + 256;
 }
 
 BFHIP_EXPORT int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const int *in_shape,
                                      const int *ksize, const int *dilation, int32_t *pair_fwd,
-                                     int32_t *n_pairs_dev, void *workspace, size_t workspace_bytes,
-                                     void *stream_) {
+                                     int32_t *n_pairs_dev, uint32_t *row_mask, int32_t *perm, void *workspace,
+                                     size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ConvGeom G;
   BFHIP_REQUIRE(N >= 0, "rulebook_subm: N < 0");
   BFHIP_REQUIRE(make_geom(B, in_shape, ksize, nullptr, nullptr, dilation, true, G) == 0,
                 "rulebook_subm: bad geometry (B*X*Y*Z must be < 2^31, kernel volume <= 64)");
-  BFHIP_REQUIRE(n_pairs_dev, "rulebook_subm: n_pairs_dev is null");
-  if (hipMemsetAsync(n_pairs_dev, 0, 64 * sizeof(int), stream) != hipSuccess) return check_launch("rulebook_subm memset");
+  BFHIP_REQUIRE(!(row_mask || perm) || G.KV <= 32, "rulebook_subm: row masks need a kernel volume <= 32");
+  BFHIP_REQUIRE(!perm || row_mask, "rulebook_subm: perm without row_mask");
+  if (n_pairs_dev && hipMemsetAsync(n_pairs_dev, 0, 64 * sizeof(int), stream) != hipSuccess) return check_launch("rulebook_subm memset");
   if (N == 0) return BFHIP_OK;
   BFHIP_REQUIRE(indices && pair_fwd && ((uintptr_t)indices % 16) == 0, "rulebook_subm: null/unaligned pointer");
   if (workspace_bytes < bfhip_rulebook_subm_workspace_bytes(N) || !workspace) {
@@ -1472,22 +1639,37 @@ BFHIP_EXPORT int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const
   Workspace ws(workspace, workspace_bytes);
   unsigned cap = table_cap(N);
   int2 *table = ws.take<int2>(cap);
+  size_t sort_bytes = bfhip_rulebook_sort_rows_workspace_bytes(N, G.KV);
+  SortScratch ss(ws.take<char>(sort_bytes), sort_bytes, N);
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
-  {
-    long long words = (long long)cap * 2;
-    hipLaunchKernelGGL(fill_pair_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, stream, table, (int)cap);
-    (void)words;
-  }
-  hipMemsetAsync(pair_fwd, 0xff, (size_t)G.KV * N * sizeof(int), stream);
+  hipLaunchKernelGGL(fill_pair_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, stream, table, (int)cap);
   hipLaunchKernelGGL(subm_insert_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, stream, (const int4 *)indices, N, G,
                      table, cap - 1);
-  // odd kernel sizes with unit dilation symmetry: probe offsets 0..KV/2 only
-  const int symmetric = (G.k0 % 2 == 1) && (G.k1 % 2 == 1) && (G.k2 % 2 == 1);
-  const int nk = symmetric ? G.KV / 2 + 1 : G.KV;
-  hipLaunchKernelGGL(subm_pairs_kernel, dim3(ceil_div(N, 256), nk), dim3(256), 0, stream, (const int4 *)indices, N,
-                     G, table, cap - 1, pair_fwd, n_pairs_dev, symmetric);
+  hipError_t e = hipSuccess;
+  if (G.k0 * G.k1 <= 16 && G.KV <= 32) {
+    dim3 block(64, G.k0 * G.k1);
+    unsigned *iota = perm ? ss.iota : nullptr, *keys = perm ? ss.keys : nullptr;
+    if (G.k2 == 3)
+      hipLaunchKernelGGL(subm_pairs_rows_kernel<3>, dim3(ceil_div(N, 64)), block, 0, stream, (const int4 *)indices, N, G, table,
+                         cap - 1, pair_fwd, row_mask, iota, keys, sort_regions(G.KV), n_pairs_dev);
+    else
+      hipLaunchKernelGGL(subm_pairs_rows_kernel<0>, dim3(ceil_div(N, 64)), block, 0, stream, (const int4 *)indices, N, G, table,
+                         cap - 1, pair_fwd, row_mask, iota, keys, sort_regions(G.KV), n_pairs_dev);
+  } else {
+    // wide kernels: one thread per (row, offset) over the lower half of the offsets, mirrored writes (pre-filled table)
+    (void)hipMemsetAsync(pair_fwd, 0xff, (size_t)G.KV * N * sizeof(int), stream);
+    const int symmetric = (G.k0 % 2 == 1) && (G.k1 % 2 == 1) && (G.k2 % 2 == 1);
+    const int nk = symmetric ? G.KV / 2 + 1 : G.KV;
+    hipLaunchKernelGGL(subm_pairs_kernel, dim3(ceil_div(N, 256), nk), dim3(256), 0, stream, (const int4 *)indices, N,
+                       G, table, cap - 1, pair_fwd, n_pairs_dev, symmetric);
+    if (row_mask)
+      hipLaunchKernelGGL(row_mask_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, stream, pair_fwd, N, G.KV, N, row_mask, ss.iota,
+                         ss.keys, sort_regions(G.KV));
+  }
+  if (perm) e = ss.sort(N, G.KV, perm, stream);
   prof_end(&ps);
+  if (e != hipSuccess) { set_error("rulebook_subm: sort: %s", hipGetErrorString(e)); return BFHIP_E_LAUNCH; }
   return check_launch("rulebook_subm");
 }
 
@@ -1527,8 +1709,8 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_count(const int32_t *indices, int N, cons
   int *blk = ws.take<int>(nb + 1);
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
-  hipMemsetAsync(bitmap, 0, nwords * sizeof(unsigned), stream);
-  hipMemsetAsync(counts_dev, 0, 65 * sizeof(int), stream);
+  (void)hipMemsetAsync(bitmap, 0, nwords * sizeof(unsigned), stream);
+  (void)hipMemsetAsync(counts_dev, 0, 65 * sizeof(int), stream);
   if (N > 0) {
     hipLaunchKernelGGL(sparse_mark_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, n_in_dev, G, bitmap);
   }
@@ -1565,49 +1747,78 @@ BFHIP_EXPORT int bfhip_rulebook_sparse_out_indices(int B, const int *in_shape, c
   return check_launch("rulebook_sparse_out_indices");
 }
 
+// mask_fwd / perm_fwd (output rows) and mask_bwd / perm_bwd (input rows), optional, KV <= 32: what bfhip_rulebook_sort_rows gives
+// for pair_fwd and pair_bwd; the backward ones leave with the pair kernel itself.  sort_workspace:
+// bfhip_rulebook_sort_rows_workspace_bytes(max(N, n_out), KV) bytes (only needed with the masks).
 BFHIP_EXPORT int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *in_shape,
                                             const int *ksize, const int *stride, const int *padding,
                                             const int *dilation, int n_out, int32_t *out_indices,
                                             int32_t *pair_fwd, int32_t *pair_bwd, int32_t *counts_dev,
+                                            uint32_t *mask_fwd, int32_t *perm_fwd, uint32_t *mask_bwd, int32_t *perm_bwd,
+                                            void *sort_workspace, size_t sort_workspace_bytes,
                                             void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ConvGeom G;
   BFHIP_REQUIRE(make_geom(B, in_shape, ksize, stride, padding, dilation, false, G) == 0, "rulebook_sparse: bad geometry");
   BFHIP_REQUIRE(N >= 0 && n_out >= 0, "rulebook_sparse_fill: bad sizes");
   if (N == 0 || n_out == 0) return BFHIP_OK;
-  BFHIP_REQUIRE(indices && out_indices && pair_fwd && pair_bwd && counts_dev, "rulebook_sparse_fill: null pointer");
+  BFHIP_REQUIRE(indices && out_indices && pair_fwd && pair_bwd, "rulebook_sparse_fill: null pointer");
   BFHIP_REQUIRE(((uintptr_t)indices % 16) == 0 && ((uintptr_t)out_indices % 16) == 0, "rulebook_sparse_fill: indices must be 16-byte aligned");
+  const bool masks = mask_fwd || mask_bwd;
+  BFHIP_REQUIRE(!masks || (mask_fwd && mask_bwd && G.KV <= 32), "rulebook_sparse_fill: row masks come in pairs and need a kernel volume <= 32");
+  BFHIP_REQUIRE((!perm_fwd && !perm_bwd) || (masks && perm_fwd && perm_bwd), "rulebook_sparse_fill: perms need the masks (and come in pairs)");
   size_t need = bfhip_rulebook_sparse_workspace_bytes(B, in_shape, ksize, stride, padding, dilation);
   if (workspace_bytes < need || !workspace) { set_error("rulebook_sparse_fill: workspace too small"); return BFHIP_E_WORKSPACE; }
+  const int n_sort = N > n_out ? N : n_out;
+  if (masks && (!sort_workspace || sort_workspace_bytes < bfhip_rulebook_sort_rows_workspace_bytes(n_sort, G.KV))) {
+    set_error("rulebook_sparse_fill: sort workspace too small");
+    return BFHIP_E_WORKSPACE;
+  }
   long long cells = (long long)B * G.out0 * G.out1 * G.out2;
   long long nwords = (cells + 31) / 32;
   Workspace ws(workspace, workspace_bytes);
   unsigned *bitmap = ws.take<unsigned>(nwords);
   int *word_prefix = ws.take<int>(nwords);
+  int *n_pairs = counts_dev ? counts_dev + 1 : nullptr;
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
-  hipMemsetAsync(pair_fwd, 0xff, (size_t)G.KV * n_out * sizeof(int), stream);
+  (void)hipMemsetAsync(pair_fwd, 0xff, (size_t)G.KV * n_out * sizeof(int), stream);
   // n_out may be a capacity (true count only on the device): rows the kernel below does not reach stay inactive (-1)
-  hipMemsetAsync(out_indices, 0xff, (size_t)n_out * sizeof(int4), stream);
+  (void)hipMemsetAsync(out_indices, 0xff, (size_t)n_out * sizeof(int4), stream);
   hipLaunchKernelGGL(sparse_out_indices_kernel, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream, bitmap, word_prefix,
                      nwords, G, n_out, (int4 *)out_indices);
-  hipLaunchKernelGGL(sparse_pairs_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, G,
-                     bitmap, word_prefix, n_out, pair_fwd, pair_bwd, counts_dev + 1);
+  hipError_t e = hipSuccess;
+  if (G.k0 * G.k1 <= 16 && G.KV <= 32) {
+    unsigned *iota = nullptr, *keys = nullptr;
+    SortScratch sb(masks ? sort_workspace : nullptr, masks ? sort_workspace_bytes : 0, masks ? N : 0);
+    if (perm_bwd) { iota = sb.iota; keys = sb.keys; }
+    dim3 block(64, G.k0 * G.k1);
+    if (G.k2 == 3)
+      hipLaunchKernelGGL(sparse_pairs_rows_kernel<3>, dim3(ceil_div(N, 64)), block, 0, stream, (const int4 *)indices, N, G, bitmap,
+                         word_prefix, n_out, pair_fwd, pair_bwd, mask_bwd, iota, keys, sort_regions(G.KV), n_pairs);
+    else
+      hipLaunchKernelGGL(sparse_pairs_rows_kernel<0>, dim3(ceil_div(N, 64)), block, 0, stream, (const int4 *)indices, N, G, bitmap,
+                         word_prefix, n_out, pair_fwd, pair_bwd, mask_bwd, iota, keys, sort_regions(G.KV), n_pairs);
+    if (perm_bwd) e = sb.sort(N, G.KV, perm_bwd, stream);
+  } else {
+    hipLaunchKernelGGL(sparse_pairs_kernel, dim3(ceil_div(N, 256), G.KV), dim3(256), 0, stream, (const int4 *)indices, N, G,
+                       bitmap, word_prefix, n_out, pair_fwd, pair_bwd, n_pairs);
+    if (masks) {
+      SortScratch sb(sort_workspace, sort_workspace_bytes, N);
+      hipLaunchKernelGGL(row_mask_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, stream, pair_bwd, N, G.KV, N, mask_bwd, sb.iota,
+                         sb.keys, sort_regions(G.KV));
+      if (perm_bwd) e = sb.sort(N, G.KV, perm_bwd, stream);
+    }
+  }
+  if (masks && e == hipSuccess) {
+    SortScratch sf(sort_workspace, sort_workspace_bytes, n_out);
+    hipLaunchKernelGGL(row_mask_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, stream, pair_fwd, n_out, G.KV, n_out, mask_fwd,
+                       sf.iota, sf.keys, sort_regions(G.KV));
+    if (perm_fwd) e = sf.sort(n_out, G.KV, perm_fwd, stream);
+  }
   prof_end(&ps);
+  if (e != hipSuccess) { set_error("rulebook_sparse_fill: sort: %s", hipGetErrorString(e)); return BFHIP_E_LAUNCH; }
   return check_launch("rulebook_sparse_fill");
-}
-
-// Row masks + mask-sorted row permutation of a pair table (for tile-level offset skipping).
-static inline size_t sort32_bytes(int n, int bits) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs<rocprim::default_config, unsigned *, unsigned *, unsigned *, unsigned *>(
-      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, bits, 0);
-  return bytes;
-}
-
-BFHIP_EXPORT size_t bfhip_rulebook_sort_rows_workspace_bytes(int n_rows, int KV) {
-  if (n_rows <= 0) return 256;
-  return 3 * align_up((size_t)n_rows * 4, 256) + align_up(sort32_bytes(n_rows, 32), 256) + 256;
 }
 
 BFHIP_EXPORT int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, int n_rows, uint32_t *row_mask,
@@ -1617,22 +1828,14 @@ BFHIP_EXPORT int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, 
   if (n_rows == 0) return BFHIP_OK;
   BFHIP_REQUIRE(pairs && row_mask, "rulebook_sort_rows: null pointer");
   if (workspace_bytes < bfhip_rulebook_sort_rows_workspace_bytes(n_rows, KV) || !workspace) { set_error("rulebook_sort_rows: workspace too small"); return BFHIP_E_WORKSPACE; }
-  Workspace ws(workspace, workspace_bytes);
-  unsigned *iota = ws.take<unsigned>(n_rows), *keys_out = ws.take<unsigned>(n_rows), *keys = ws.take<unsigned>(n_rows);
-  // Sort key = (region of the row, mask): rows come in voxel order, so a region is a slab of space.  With the gather-GEMM's
-  // XCD-chunked block order each XCD then walks one region and the neighbour rows it gathers stay in its own 4 MiB L2
-  // (forward gather-GEMM of the encoder's layers 15-25 % faster than with a pure mask sort, tools/gemm_micro.py; 16 or
-  // 32 regions measured no better).  Tiles still share their offsets inside a region.
-  const int rbits = KV + 3 <= 32 ? 3 : 0;
-  const int nreg = 1 << rbits;
-  size_t sb = sort32_bytes(n_rows, 32);
-  char *tmp = ws.take<char>(sb);
+  SortScratch sc(workspace, workspace_bytes, n_rows);
   ProfScope ps;
   prof_begin(BFHIP_OP_RULEBOOK, stream, &ps);
-  hipLaunchKernelGGL(row_mask_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, stream, pairs, ld, KV, n_rows, row_mask, iota, keys, nreg);
+  hipLaunchKernelGGL(row_mask_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, stream, pairs, ld, KV, n_rows, row_mask, sc.iota,
+                     sc.keys, sort_regions(KV));
   hipError_t e = hipSuccess;
   if (perm)  // perm == NULL: masks only
-    e = rocprim::radix_sort_pairs(tmp, sb, keys, keys_out, iota, (unsigned *)perm, (size_t)n_rows, 0, KV + rbits, stream);
+    e = sc.sort(n_rows, KV, perm, stream);
   prof_end(&ps);
   if (e != hipSuccess) { set_error("rulebook_sort_rows: sort: %s", hipGetErrorString(e)); return BFHIP_E_LAUNCH; }
   return check_launch("rulebook_sort_rows");

@@ -42,7 +42,7 @@ class IndiceData:
     """Rulebook of one convolution (what spconv keeps in `indice_dict[indice_key]`)."""
 
     def __init__(self, out_indices, pair_fwd, pair_bwd, n_pairs, is_subm, out_spatial_shape, ksize, stride, padding,
-                 dilation, n_out_dev=None):
+                 dilation, n_out_dev=None, sorted_rows=None):
         self.n_out_dev = n_out_dev          # static capacity mode: true N_out (device i32[1]); out_indices has capacity rows
         self.out_indices = out_indices      # i32[N_out, 4]
         self.pair_fwd = pair_fwd            # i32[KV, N_out]
@@ -51,12 +51,21 @@ class IndiceData:
         self.is_subm = is_subm
         self.out_spatial_shape = out_spatial_shape
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
-        # mask-sorted row orders (tile-level offset skipping): forward table and, for strided convs, backward table
-        self.mask_fwd, self.perm_fwd = sort_rows(pair_fwd)
-        self.mask_bwd, self.perm_bwd = sort_rows(pair_bwd) if pair_bwd is not None else (None, None)
+        # mask-sorted row orders (tile-level offset skipping): forward table and, for strided convs, backward table.  The
+        # rulebook builders hand them over (made by the launches that fill the tables); sort_rows is the stand-alone form.
+        if sorted_rows is not None:
+            self.mask_fwd, self.perm_fwd, self.mask_bwd, self.perm_bwd = sorted_rows
+        else:
+            self.mask_fwd, self.perm_fwd = sort_rows(pair_fwd)
+            self.mask_bwd, self.perm_bwd = sort_rows(pair_bwd) if pair_bwd is not None else (None, None)
 
 
-# mask-sorted row order for the gather-GEMM (tile-level offset skipping); masks alone are always computed
+# Mask-sorted row order for the gather-GEMM (tile-level offset skipping); the masks alone are always computed.  Measured at
+# the benchmark's sizes (batch 4): the 12 sorts of a pass cost 0.52 ms of launch-bound work and save 0.15 ms of gather-GEMM
+# time (forward 1.02 -> 0.98, dgrad 1.00 -> 0.89 ms).  ALONE, the LiDAR pass is faster without them (6.35 vs 7.06 ms,
+# tools/sparse_micro.py); inside the full training step, where the branch runs beside the camera stream and the sorts'
+# small launches fill gaps while the GEMM savings free CUs, the step is 0.25 ms faster WITH them (34.83 vs 35.08 and 36.03 vs
+# 36.28 ms, tools/ab_step.sh, same box) -- hence on by default; BFHIP_SPCONV_SORT=0 for LiDAR-only deployments.
 SORT_ROWS = os.environ.get("BFHIP_SPCONV_SORT", "1") == "1"
 # weight gradient of layers whose input channel count is not a multiple of 4: zero-pad the input for the MFMA kernel
 PAD_WGRAD_INPUT = os.environ.get("BFHIP_SPCONV_PAD_WGRAD", "1") == "1"
@@ -79,20 +88,28 @@ def sort_rows(pairs):
     return mask, perm
 
 
+def _mask_perm(n, dev):
+    mask = torch.empty(n, dtype=torch.int32, device=dev)
+    return mask, (torch.empty(n, dtype=torch.int32, device=dev) if SORT_ROWS else None)
+
+
 def build_subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation):
     N = indices.shape[0]
     kv = ksize[0] * ksize[1] * ksize[2]
     dev = indices.device
     pair_fwd = torch.empty((kv, N), dtype=torch.int32, device=dev)
-    n_pairs = torch.zeros(64, dtype=torch.int32, device=dev)  # 64 spread counters; total = sum
+    n_pairs = torch.empty(64, dtype=torch.int32, device=dev)  # 64 spread counters (zeroed by the call); total = sum
+    fused = kv <= 32  # row masks + sorted order from the launch that fills the table
+    mask, perm = _mask_perm(N, dev) if fused else (None, None)
     lib = _lib.load()
     ws = _workspace(dev, lib.bfhip_rulebook_subm_workspace_bytes(N), "rule")
     with torch.cuda.device(dev):
         rc = lib.bfhip_rulebook_subm(_lib.ptr(indices), N, batch_size, _lib.host_i32(spatial_shape), _lib.host_i32(ksize),
-                                     _lib.host_i32(dilation), _lib.ptr(pair_fwd), _lib.ptr(n_pairs), _lib.ptr(ws),
-                                     ws.numel(), _lib.stream_of(indices))
+                                     _lib.host_i32(dilation), _lib.ptr(pair_fwd), _lib.ptr(n_pairs), _lib.ptr(mask),
+                                     _lib.ptr(perm), _lib.ptr(ws), ws.numel(), _lib.stream_of(indices))
     _lib.check(rc, "rulebook_subm")
-    return IndiceData(indices, pair_fwd, None, n_pairs, True, list(spatial_shape), ksize, [1, 1, 1], None, dilation)
+    return IndiceData(indices, pair_fwd, None, n_pairs, True, list(spatial_shape), ksize, [1, 1, 1], None, dilation,
+                      sorted_rows=(mask, perm, None, None) if fused else None)
 
 
 def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
@@ -239,13 +256,19 @@ def build_sparse_rulebook(indices, batch_size, spatial_shape, ksize, stride, pad
         out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
         pair_fwd = torch.empty((kv, n_out), dtype=torch.int32, device=dev)
         pair_bwd = torch.empty((kv, N), dtype=torch.int32, device=dev)
+        fused = kv <= 32 and N > 0 and n_out > 0
+        mask_f, perm_f = _mask_perm(n_out, dev) if fused else (None, None)
+        mask_b, perm_b = _mask_perm(N, dev) if fused else (None, None)
+        sws = _workspace(dev, lib.bfhip_rulebook_sort_rows_workspace_bytes(max(N, n_out), kv), "sort") if fused else None
         rc = lib.bfhip_rulebook_sparse_fill(_lib.ptr(indices), N, batch_size, *geo, n_out, _lib.ptr(out_indices),
-                                            _lib.ptr(pair_fwd), _lib.ptr(pair_bwd), _lib.ptr(counts), _lib.ptr(ws),
-                                            ws.numel(), stream)
+                                            _lib.ptr(pair_fwd), _lib.ptr(pair_bwd), _lib.ptr(counts), _lib.ptr(mask_f),
+                                            _lib.ptr(perm_f), _lib.ptr(mask_b), _lib.ptr(perm_b), _lib.ptr(sws),
+                                            sws.numel() if fused else 0, _lib.ptr(ws), ws.numel(), stream)
     _lib.check(rc, "rulebook_sparse_fill")
     return IndiceData(out_indices, pair_fwd, pair_bwd, counts[1:], False,
                       conv_out_shape(spatial_shape, ksize, stride, padding, dilation), ksize, stride, padding, dilation,
-                      n_out_dev=plan.n_out_dev if plan is not None else None)
+                      n_out_dev=plan.n_out_dev if plan is not None else None,
+                      sorted_rows=(mask_f, perm_f, mask_b, perm_b) if fused else None)
 
 
 def _bf16_ok(weight, transpose):

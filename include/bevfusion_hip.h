@@ -210,8 +210,11 @@ int bfhip_conv_out_shape(const int *in_shape, const int *ksize, const int *strid
                          const int *padding, const int *dilation, int *out_shape);
 size_t bfhip_rulebook_subm_workspace_bytes(int N);
 int bfhip_rulebook_subm(const int32_t *indices, int N, int B, const int *in_shape, const int *ksize,
-                        const int *dilation, int32_t *pair_fwd, int32_t *n_pairs_dev,
-                        void *workspace, size_t workspace_bytes, void *stream);
+                        const int *dilation, int32_t *pair_fwd, int32_t *n_pairs_dev, uint32_t *row_mask,
+                        int32_t *perm, void *workspace, size_t workspace_bytes, void *stream);
+/* row_mask / perm (optional, kernel volume <= 32): the table's row masks and sorted row order (see
+ * bfhip_rulebook_sort_rows below), produced by the launch that fills the table instead of a second pass over it.
+ * n_pairs_dev is optional (NULL: no pair statistics). */
 size_t bfhip_rulebook_sparse_workspace_bytes(int B, const int *in_shape, const int *ksize,
                                              const int *stride, const int *padding,
                                              const int *dilation);
@@ -228,7 +231,11 @@ int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *
                                const int *ksize, const int *stride, const int *padding,
                                const int *dilation, int n_out, int32_t *out_indices,
                                int32_t *pair_fwd, int32_t *pair_bwd, int32_t *counts_dev,
+                               uint32_t *mask_fwd, int32_t *perm_fwd, uint32_t *mask_bwd, int32_t *perm_bwd,
+                               void *sort_workspace, size_t sort_workspace_bytes,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* mask_fwd / perm_fwd (over the output rows, from pair_fwd) and mask_bwd / perm_bwd (over the input rows, from pair_bwd):
+ * optional, kernel volume <= 32; sort_workspace = bfhip_rulebook_sort_rows_workspace_bytes(max(N, n_out), KV) bytes. */
 /* row_mask[n] bit k = (pairs[k][n] >= 0); perm = rows stably sorted by (eighth of the row range, mask), so that the
  * 16 rows of an MFMA tile share their kernel offsets and whole offsets are skipped per tile (cf. spconv's
  * mask_argsort, projects/SparseConvolution/sparse_functional.py:139-162) while consecutive tiles stay in one slab of

@@ -29,7 +29,14 @@ def _voxel_indices(dev, n_points=40000, batch=2):
     return np.concatenate(out, 0)
 
 
-def test_subm_rulebook_bit_exact(dev):
+@pytest.fixture
+def sorted_rows(monkeypatch):
+    """The mask-sorted row orders are opt-in (BFHIP_SPCONV_SORT=1); the tests of that path switch them on."""
+    from bevfusion_amd import spconv
+    monkeypatch.setattr(spconv, "SORT_ROWS", True)
+
+
+def test_subm_rulebook_bit_exact(dev, sorted_rows):
     idx = _voxel_indices(dev)
     shape = [1440, 1440, 41]
     want = oracle.rulebook_subm(idx, shape, 3)
@@ -40,11 +47,23 @@ def test_subm_rulebook_bit_exact(dev):
     pf = data.pair_fwd.cpu().numpy()
     k, n = np.nonzero(pf >= 0)
     assert np.array_equal(pf[26 - k, pf[k, n]], n)
+    _check_fused_sorted_rows(data)
+
+
+def _check_fused_sorted_rows(data):
+    """The row masks / sorted orders that leave with the table-filling launches equal the stand-alone pass over the table."""
+    from bevfusion_amd.spconv import sort_rows
+    for table, mask, perm in ((data.pair_fwd, data.mask_fwd, data.perm_fwd), (data.pair_bwd, data.mask_bwd, data.perm_bwd)):
+        if table is None:
+            continue
+        want_mask, want_perm = sort_rows(table)
+        assert torch.equal(mask, want_mask)
+        assert torch.equal(perm, want_perm)
 
 
 @pytest.mark.parametrize("shape,ksize,stride,padding", [([1440, 1440, 41], 3, 2, 1), ([360, 360, 11], 3, 2, (1, 1, 0)),
                                                         ([180, 180, 5], (1, 1, 3), (1, 1, 2), 0)])
-def test_sparse_rulebook_bit_exact(dev, shape, ksize, stride, padding):
+def test_sparse_rulebook_bit_exact(dev, sorted_rows, shape, ksize, stride, padding):
     if shape[0] == 1440:
         idx = _voxel_indices(dev)
     else:
@@ -59,6 +78,7 @@ def test_sparse_rulebook_bit_exact(dev, shape, ksize, stride, padding):
     assert np.array_equal(data.pair_fwd.cpu().numpy(), pf)
     assert np.array_equal(data.pair_bwd.cpu().numpy(), pb)
     assert int(data.n_pairs.sum().item()) == (pf >= 0).sum()
+    _check_fused_sorted_rows(data)
 
 
 @pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (32, 32), (16, 32), (32, 64), (64, 64), (128, 128), (7, 9)])
@@ -77,6 +97,28 @@ def test_conv_fwd_bwd_vs_oracle(dev, cin, cout):
     d_in, d_w = oracle.spconv_bwd(feats, w, g.cpu().numpy(), pair)
     assert rel_err(x.features.grad.cpu().numpy(), d_in) < TOL
     assert rel_err(conv.weight.grad.cpu().numpy(), d_w) < TOL
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64)])
+def test_conv_with_mask_sorted_rows(dev, sorted_rows, cin, cout):
+    """The opt-in mask-sorted tile order (BFHIP_SPCONV_SORT=1) changes which rows share a tile, not any row's sum."""
+    from bevfusion_amd import spconv
+    B, shape, n = 2, (40, 36, 9), 6000
+    idx, feats = random_sparse(B, shape, n, cin, seed=5)
+    res = []
+    for srt in (True, False):
+        spconv.SORT_ROWS = srt
+        torch.manual_seed(0)
+        conv = SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False).to(dev)
+        sub = SubMConv3d(cout, cout, 3, padding=1, bias=False, indice_key="s").to(dev)
+        x = SparseConvTensor(torch.from_numpy(feats).to(dev).requires_grad_(True), torch.from_numpy(idx).to(dev), shape, B)
+        out = sub(conv(x))
+        assert (out.indice_dict["s"].perm_fwd is not None) == srt
+        out.features.square().sum().backward()
+        res.append((out.features.detach().clone(), x.features.grad.clone(), conv.weight.grad.clone(), sub.weight.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2:], res[1][2:]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5   # fp32 summation order of the weight gradient only
 
 
 def test_strided_conv_fwd_bwd_vs_oracle(dev):
@@ -467,7 +509,7 @@ def test_wgrad_abi_geometries_vs_fp64(dev, cin, cout, kv, n_rows, use_perm):
         assert torch.equal(dw, dw2)
 
 
-def test_sort_rows_is_region_major_mask_sort(dev):
+def test_sort_rows_is_region_major_mask_sort(dev, sorted_rows):
     """bfhip_rulebook_sort_rows: row_mask bit k = pair present; perm = stable sort by (eighth of the row range, mask)."""
     from bevfusion_amd.spconv import sort_rows
     rs = np.random.RandomState(4)
