@@ -30,7 +30,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __attribute__((aligned(64))) unsigned g_zero_page[16];  // source of every padded / out-of-range piece
+// Source of every padded / out-of-range / hole piece.  64 KB, and a wave reads from ITS OWN 64-byte line of it (zero_src()):
+// with a single shared line every hole of every workgroup was a request to the same L2 channel -- at ~1 request per clock
+// that one channel set the pace of the sparse kernels, where half of the pieces are holes (128 -> 128 SubM layer: 72 us with
+// one line, whatever the prefetch depth).
+constexpr int kZeroLines = 1024;
+__device__ __attribute__((aligned(4096))) unsigned g_zero_page[kZeroLines * 16];
+
+__device__ __forceinline__ const unsigned short *zero_src() {
+  const unsigned line = (blockIdx.x * 8u + (threadIdx.x >> 6)) & (unsigned)(kZeroLines - 1);
+  return (const unsigned short *)(g_zero_page + line * 16u);
+}
 
 struct ConvGeom {
   // gathered tensor [N, H, W, C] (pixel pitch ldx elements); GEMM rows = pixels of an [N, OH, OW] grid
@@ -72,7 +82,7 @@ __device__ __forceinline__ void build_tap_table(unsigned *taps, const ConvGeom &
 // division (transposed strides are powers of two: shift + mask), 32-bit element offsets (tensors < 2^31 elements).
 template <bool TR>
 __device__ __forceinline__ const bf16_t *piece_src(const bf16_t *x, const ConvGeom &g, bool row_ok, int nb, int hb, int wb,
-                                                   unsigned info) {
+                                                   unsigned info, const bf16_t *zsrc) {
   const int dh = info >> 24, dw = (info >> 16) & 0xff, ci = info & 0xffff;
   int ih, iw;
   bool ok = row_ok;
@@ -87,7 +97,89 @@ __device__ __forceinline__ const bf16_t *piece_src(const bf16_t *x, const ConvGe
   }
   ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
   const unsigned off = (unsigned)(nb + ih * g.W + iw) * (unsigned)g.ldx + (unsigned)ci;
-  return ok ? x + off : (const bf16_t *)g_zero_page;
+  return ok ? x + off : zsrc;
+}
+
+// ---- epilogue of the implicit-GEMM kernel: (optional) BatchNorm statistics of the raw accumulators, then
+// accumulators -> LDS [BM][BN] -> 16-byte coalesced stores.  M rows, Kout columns, row pitch ldy.
+template <int WM, int WN, bool OUT_F32>
+__device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[2][WN], unsigned char *smem, int tm, long long m0, int n0,
+                                               long long M, int Kout, int ldy, const float *__restrict__ bias,
+                                               void *__restrict__ y, float *__restrict__ stat_partial) {
+  constexpr int NTHREADS = WM * 128;
+  constexpr int BN = WN * 64, BM = WM * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  __syncthreads();  // every wave is done with the staging buffers: reuse them for the epilogue
+
+  // ---- BatchNorm statistics of the raw accumulators (rows beyond M are exact zeros): per-column sum / sum of squares,
+  //      one partial row per 128 rows of the tile
+  if (stat_partial) {
+    float *sred = (float *)(smem);  // [WM][BN][2]
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { float v = acc[mi][ni][r]; s += v; s2 += v * v; }
+      s += __shfl_xor(s, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0) {
+        int col = wn * (WN * 32) + ni * 32 + l31;
+        sred[(wm * BN + col) * 2 + 0] = s;
+        sred[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    const int total_rows = (int)((M + 127) / 128);
+    for (int e = tid; e < (WM / 2) * BN; e += NTHREADS) {
+      const int half = e / BN, col = e - half * BN;
+      const int prow = tm * (WM / 2) + half;
+      if (n0 + col < Kout && prow < total_rows) {
+        const float *p0 = sred + ((half * 2) * BN + col) * 2, *p1 = sred + ((half * 2 + 1) * BN + col) * 2;
+        stat_partial[((size_t)prow * 2 + 0) * Kout + n0 + col] = p0[0] + p1[0];
+        stat_partial[((size_t)prow * 2 + 1) * Kout + n0 + col] = p0[1] + p1[1];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- output: accumulators -> LDS [BM][BN] (row-major) -> 16-byte coalesced stores
+  constexpr int ESZ = OUT_F32 ? 4 : 2;
+  constexpr int ROWB = BN * ESZ;
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    const int col = wn * (WN * 32) + ni * 32 + l31;
+    const float bv = (bias && n0 + col < Kout) ? bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = acc[mi][ni][r] + bv;
+        if (OUT_F32) *(float *)(smem + row * ROWB + col * 4) = v;
+        else *(bf16_t *)(smem + row * ROWB + col * 2) = (bf16_t)rne_bf16(v);
+      }
+  }
+  __syncthreads();
+  constexpr int CPR = ROWB / 16;  // 16-byte pieces per row
+  constexpr int EPC = 16 / ESZ;   // elements per piece
+  for (int idx = tid; idx < BM * CPR; idx += NTHREADS) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    const long long m = m0 + row;
+    const int col = n0 + c * EPC;
+    if (m >= M || col >= Kout) continue;
+    unsigned char *dst = (unsigned char *)y + ((size_t)m * ldy + col) * ESZ;
+    const unsigned char *src = smem + row * ROWB + c * 16;
+    if (col + EPC <= Kout && (((uintptr_t)dst) & 15) == 0) *(uint4 *)dst = *(const uint4 *)src;
+    else
+      for (int e = 0; e < EPC && col + e < Kout; ++e) {
+        if (OUT_F32) ((float *)dst)[e] = ((const float *)src)[e];
+        else ((bf16_t *)dst)[e] = ((const bf16_t *)src)[e];
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
@@ -152,6 +244,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
   __syncthreads();  // tap table ready
 
   const int nt = (g.nq + 7) >> 3;
+  const bf16_t *zsrc = zero_src();
   auto stage = [&](int t, int buf) {  // exactly GL DMA instructions per wave (the counted waits rely on it)
     unsigned char *dA = smem + buf * S_BYTES + (w * 32) * 128;
     unsigned char *dB = smem + buf * S_BYTES + A_BYTES + (w * (NB * 8)) * 128;
@@ -159,14 +252,14 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
     for (int i = 0; i < 4; ++i) {
       const int swz = (i * 4 + (lane >> 4)) & 7;  // ((row >> 1) & 7) of row = w*32 + i*8 + lrow
       const int q = t * 8 + (lpos ^ swz);
-      const bf16_t *src = q < g.nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q]) : (const bf16_t *)g_zero_page;
+      const bf16_t *src = q < g.nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q], zsrc) : zsrc;
       glds16(src, dA + i * 1024);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int swz = ((w * (NB * 8) + i * 8 + lrow) >> 1) & 7;
       const int q = t * 8 + (lpos ^ swz);
-      const bf16_t *src = (wrow[i] && q < g.nq) ? wrow[i] + (size_t)q * 8 : (const bf16_t *)g_zero_page;
+      const bf16_t *src = (wrow[i] && q < g.nq) ? wrow[i] + (size_t)q * 8 : zsrc;
       glds16(src, dB + i * 1024);
     }
   };
@@ -193,8 +286,9 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
     else if (STAGES == 3 || nt - 1 - t == 1) wait_vmcnt<GL>();
     else wait_vmcnt<2 * GL>();
     __builtin_amdgcn_s_barrier();  // all of step t is in LDS; every wave is done reading step t - 1
-    if (t + STAGES - 1 < nt) stage(t + STAGES - 1, nbuf);
     const unsigned char *pA = smem + buf * S_BYTES + aoff, *pB = smem + buf * S_BYTES + boff;
+    if (t + STAGES - 1 < nt) stage(t + STAGES - 1, nbuf);  // before the MFMAs: issuing it after the first K quarter's MFMAs
+                                                           // (address generation in their shadow) measured 5-10 % slower
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int pos = ((2 * ks + lh) ^ rswz) << 4;
@@ -211,75 +305,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
     buf = buf + 1 == STAGES ? 0 : buf + 1;
     nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
   }
-  __syncthreads();  // every wave is done with the staging buffers: reuse them for the epilogue
-
-  // ---- BatchNorm statistics of the raw accumulators (rows beyond M are exact zeros): per-column sum / sum of squares,
-  //      one partial row per 128 rows of the tile
-  if (stat_partial) {
-    float *sred = (float *)(smem);  // [WM][BN][2]
-#pragma unroll
-    for (int ni = 0; ni < WN; ++ni) {
-      float s = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { float v = acc[mi][ni][r]; s += v; s2 += v * v; }
-      s += __shfl_xor(s, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lh == 0) {
-        int col = wn * (WN * 32) + ni * 32 + l31;
-        sred[(wm * BN + col) * 2 + 0] = s;
-        sred[(wm * BN + col) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    const int total_rows = (int)((g.M + 127) / 128);
-    for (int e = tid; e < (WM / 2) * BN; e += NTHREADS) {
-      const int half = e / BN, col = e - half * BN;
-      const int prow = tm * (WM / 2) + half;
-      if (n0 + col < g.Kout && prow < total_rows) {
-        const float *p0 = sred + ((half * 2) * BN + col) * 2, *p1 = sred + ((half * 2 + 1) * BN + col) * 2;
-        stat_partial[((size_t)prow * 2 + 0) * g.Kout + n0 + col] = p0[0] + p1[0];
-        stat_partial[((size_t)prow * 2 + 1) * g.Kout + n0 + col] = p0[1] + p1[1];
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- output: accumulators -> LDS [BM][BN] (row-major) -> 16-byte coalesced stores
-  constexpr int ESZ = OUT_F32 ? 4 : 2;
-  constexpr int ROWB = BN * ESZ;
-#pragma unroll
-  for (int ni = 0; ni < WN; ++ni) {
-    const int col = wn * (WN * 32) + ni * 32 + l31;
-    const float bv = (bias && n0 + col < g.Kout) ? bias[n0 + col] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = acc[mi][ni][r] + bv;
-        if (OUT_F32) *(float *)(smem + row * ROWB + col * 4) = v;
-        else *(bf16_t *)(smem + row * ROWB + col * 2) = (bf16_t)rne_bf16(v);
-      }
-  }
-  __syncthreads();
-  constexpr int CPR = ROWB / 16;  // 16-byte pieces per row
-  constexpr int EPC = 16 / ESZ;   // elements per piece
-  for (int idx = tid; idx < BM * CPR; idx += NTHREADS) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    const long long m = m0 + row;
-    const int col = n0 + c * EPC;
-    if (m >= g.M || col >= g.Kout) continue;
-    unsigned char *dst = (unsigned char *)y + ((size_t)m * g.ldy + col) * ESZ;
-    const unsigned char *src = smem + row * ROWB + c * 16;
-    if (col + EPC <= g.Kout && (((uintptr_t)dst) & 15) == 0) *(uint4 *)dst = *(const uint4 *)src;
-    else
-      for (int e = 0; e < EPC && col + e < g.Kout; ++e) {
-        if (OUT_F32) ((float *)dst)[e] = ((const float *)src)[e];
-        else ((bf16_t *)dst)[e] = ((const bf16_t *)src)[e];
-      }
-  }
+  igemm_epilogue<WM, WN, OUT_F32>(acc, smem, tm, m0, n0, g.M, g.Kout, g.ldy, bias, y, stat_partial);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -412,15 +438,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
     pcx[i] = info & 0xffff;
     gsrc[i] = dy + ((size_t)pm[i] * wg.ldg + co);
   }
+  const bf16_t *zsrc = zero_src();
   auto stage = [&](int buf) {
     unsigned char *dG = sG + buf * T_BYTES + (w * 16) * 256, *dX = sX + buf * T_BYTES + (w * 16) * 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool rok = pm[i] < p_end;
-      glds16((rok && cok[i]) ? gsrc[i] : (const bf16_t *)g_zero_page, dG + i * 1024);
+      glds16((rok && cok[i]) ? gsrc[i] : zsrc, dG + i * 1024);
       const int ih = poh[i] * g.stride - g.pad + pdh[i], iw = pow_[i] * g.stride - g.pad + pdw[i];
       const bool ok = rok && qok[i] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-      const bf16_t *sx = ok ? x + ((size_t)((pn[i] * g.H + ih) * g.W + iw) * g.ldx + pcx[i]) : (const bf16_t *)g_zero_page;
+      const bf16_t *sx = ok ? x + ((size_t)((pn[i] * g.H + ih) * g.W + iw) * g.ldx + pcx[i]) : zsrc;
       glds16(sx, dX + i * 1024);
     }
   };
@@ -507,13 +534,14 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_tr_kernel(const bf16_t *_
     pci[i] = k8 - pk[i] * sg.Cin;
     pidx[i] = (qok[i] && row[i] < p_end) ? pairs[(size_t)pk[i] * sg.ld + row[i]] : -1;
   }
+  const bf16_t *zsrc = zero_src();
   auto stage = [&](int buf) {  // rows `row[]`, pairs `pidx[]` (already loaded)
     unsigned char *dG = sG + buf * T_BYTES + (w * 16) * 256, *dX = sX + buf * T_BYTES + (w * 16) * 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool rok = row[i] < p_end;
-      glds16((rok && cok[i]) ? dout + ((size_t)row[i] * sg.Cout + gco[i]) : (const bf16_t *)g_zero_page, dG + i * 1024);
-      glds16(pidx[i] >= 0 ? in + ((size_t)pidx[i] * sg.Cin + pci[i]) : (const bf16_t *)g_zero_page, dX + i * 1024);
+      glds16((rok && cok[i]) ? dout + ((size_t)row[i] * sg.Cout + gco[i]) : zsrc, dG + i * 1024);
+      glds16(pidx[i] >= 0 ? in + ((size_t)pidx[i] * sg.Cin + pci[i]) : zsrc, dX + i * 1024);
     }
   };
   auto advance = [&]() {  // next step's rows and their pair indices (global loads issued here, consumed by the next stage())
@@ -655,6 +683,7 @@ int spconv_wgrad_tr(const void *in, const void *dout, const int32_t *pairs, int 
                      total, (void *)dW, 0);
   return BFHIP_OK;
 }
+
 }  // namespace bfhip
 
 using namespace bfhip;

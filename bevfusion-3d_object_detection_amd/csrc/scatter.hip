@@ -290,7 +290,7 @@ BFHIP_EXPORT int bfhip_dynamic_scatter_bwd(float *grad_feats, const float *grad_
     if (workspace_bytes < bfhip_dynamic_scatter_bwd_workspace_bytes(M, C) || !workspace) { set_error("dynamic_scatter_bwd: workspace too small"); return BFHIP_E_WORKSPACE; }
     int *reduce_from = (int *)workspace;
     hipMemsetAsync(grad_feats, 0, (size_t)N * C * sizeof(float), stream);
-    hipMemsetAsync(reduce_from, 0x7f, (size_t)M * C * sizeof(int), stream);
+    (void)hipMemsetAsync(reduce_from, 0x7f, (size_t)M * C * sizeof(int), stream);
     hipLaunchKernelGGL(scatter_bwd_argmax_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, feats, voxel_feats,
                        point2voxel, total, C, reduce_from);
     long long mc = (long long)M * C;
