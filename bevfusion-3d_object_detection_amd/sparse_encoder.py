@@ -181,7 +181,7 @@ class BEVFusionSparseEncoder(nn.Module):
             x.indice_dict["_strided_plans"] = prepare_strided_rulebooks(
                 coors, batch_size, self.sparse_shape, [(m.kernel_size, m.stride, m.padding, m.dilation) for m in chain],
                 hints=self._nout_hints)
-            if len(self._nout_hints) == len(chain):
+            if len(self._nout_hints) == len(chain) and all(h > 0 for h in self._nout_hints):
                 self.update_static_caps(self._nout_hints)
         x = self.conv_input(x)
         encode_features = []

@@ -185,13 +185,16 @@ def prepare_strided_rulebooks(indices, batch_size, spatial_shape, specs, hints=N
     if not levels:
         return {}
     n_outs = torch.stack([c[0] for _, c, _, _ in levels]).tolist()  # the one host read
-    if hints is not None:
-        hints[:] = n_outs
     plans = {}
     for (key, counts, ws, cap), n_out in zip(levels, n_outs):
         if n_out > cap:
             break  # this level (and its successors, counted from a truncated input) falls back to the per-layer path
         plans[key] = StridedPlan(key, int(n_out), counts, ws)
+    if hints is not None:
+        # the count of the first overflowing level is still exact (its input was complete); the levels after it were counted
+        # from a truncated input and say nothing about the frame: no hint (0) for them, the next forward uses the loose caps
+        good = min(len(plans) + 1, len(n_outs))
+        hints[:] = n_outs[:good] + [0] * (len(n_outs) - good)
     return plans
 
 

@@ -421,6 +421,60 @@ def test_to_bev_channels_last_matches_nchw(dev):
     assert torch.allclose(f1.grad, f0.grad, rtol=1e-2, atol=1e-2)
 
 
+def test_presized_rulebooks_hint_overflow_falls_back(dev):
+    """The hint-capped presizing path: the caps of a forward are 1.5x the previous frame's N_out + 4096, so a frame several
+    times larger overflows them; the overflowing level and its successors (counted from a truncated input) must take the
+    per-layer path, results stay bit-equal to presizing off (forward and gradients), and the next frame is planned again."""
+    from bevfusion_amd import spconv as sp
+    from bevfusion_amd.sparse_encoder import BEVFusionSparseEncoder
+    B, shape = 2, (96, 96, 41)
+    small = random_sparse(B, shape, 1500, 5, seed=31)
+    large = random_sparse(B, shape, 40000, 5, seed=32)
+    torch.manual_seed(0)
+
+    def make():
+        torch.manual_seed(0)
+        return BEVFusionSparseEncoder(in_channels=5, sparse_shape=list(shape), norm_cfg=dict(type="BN1d", eps=0.001, momentum=0.01),
+                                      encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                                      encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, (1, 1, 0)), (0, 0)), block_type="basicblock",
+                                      return_middle_feats=True).to(dev).train()
+
+    planned_levels = []
+    orig = sp.prepare_strided_rulebooks
+
+    def spy(*a, **k):
+        plans = orig(*a, **k)
+        planned_levels.append(len(plans))
+        return plans
+
+    out = {}
+    for presize in (True, False):
+        enc = make()
+        enc.presize_rulebooks = presize
+        sp_mod_fn = sp.prepare_strided_rulebooks
+        import bevfusion_amd.sparse_encoder as se
+        se.prepare_strided_rulebooks = spy if presize else orig
+        try:
+            res = []
+            for idx, feats in (small, large, large):
+                f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+                bev, mid = enc(f, torch.from_numpy(idx).to(dev), B)
+                bev.square().mean().backward()
+                res.append((bev.detach().clone(), [m.indices.clone() for m in mid], f.grad.clone(),
+                            [p.grad.clone() for p in enc.parameters()]))
+                enc.zero_grad()
+            out[presize] = res
+        finally:
+            se.prepare_strided_rulebooks = sp_mod_fn
+    # frame 1: no hints (all 4 levels planned); frame 2: caps from the small frame overflow at the first level (nothing
+    # planned); frame 3: hints from frame 2's true counts fit again
+    assert planned_levels[0] == 4 and planned_levels[1] < 4 and planned_levels[2] == 4, planned_levels
+    for (b1, i1, g1, p1), (b0, i0, g0, p0) in zip(out[True], out[False]):
+        assert torch.equal(b1, b0) and torch.equal(g1, g0)
+        assert all(torch.equal(a, b) for a, b in zip(i1, i0))
+        assert all(torch.equal(a, b) for a, b in zip(p1, p0))
+
+
 def test_presized_strided_rulebooks_are_identical(dev):
     """Counting all strided layers up front (one host read) yields the same rulebooks and the same BEV map, bit
     for bit, as the per-layer path; a level that overflows its cap falls back to the per-layer path."""
