@@ -46,8 +46,9 @@ MIOPEN_FIND = os.environ.get("BENCH_MIOPEN_FIND", "0") == "1"
 # gradient exchange between ranks: "flat" = one all-reduce per dtype after the backward (default), "ddp" = torch DDP buckets
 GRAD_SYNC = os.environ.get("BENCH_GRAD_SYNC", "flat")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
-# the weight-gradient kernel's MFMA type (updated when the kernel moves to the bf16 MFMA)
-WGRAD_PEAK = (157.3, "fp32-input MFMA peak 157.3 TFLOP/s (v_mfma_f32_16x16x4_f32); the bf16 MFMA peak is 16x that")
+# dense matrix-core peaks (MI355X_MICROARCH.md): bf16 v_mfma_f32_32x32x16_bf16 / fp32-input v_mfma_f32_16x16x4_f32
+MFMA_PEAK_BF16 = (2500.0, "bf16 MFMA dense peak ~2500 TFLOP/s (v_mfma_f32_*_bf16)")
+MFMA_PEAK_F32 = (157.3, "fp32-input MFMA peak 157.3 TFLOP/s (v_mfma_f32_16x16x4_f32)")
 
 
 def parse():
@@ -315,17 +316,20 @@ class _ModelWorkload:
             finally:
                 sp._SparseConvFunction.forward = staticmethod(orig)
             flops = sum(2.0 * P * ci * co for P, ci, co, _, _ in layers)
-            byts = sum((ni * ci + no * co) * 4 + P * 8 + 27 * ci * co * 4 for P, ci, co, ni, no in layers)
-            # forward / dgrad run on the bf16 MFMA under bf16 autocast (layers with K % 8 == 0), wgrad always on the fp32 MFMA
-            gemm_peak = 2500.0 if self.amp else 157.3
-            note = "bf16 MFMA dense peak ~2500 TFLOP/s" if self.amp else "fp32-input MFMA peak 157.3 TFLOP/s"
-            work["spconv_fwd"] = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=gemm_peak, peak_note=note,
-                                      scope="21 gather-GEMM launches (all sparse conv layers of the step)")
-            work["spconv_bwd"] = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=gemm_peak, peak_note=note,
-                                      scope="dgrad: 20 gather-GEMM launches")
-            wg = dict(bound="mfma", flops=flops, bytes=byts, unit_peak=WGRAD_PEAK[0], peak_note=WGRAD_PEAK[1])
-            work["spconv_wgrad"] = dict(wg, scope="whole op x 21 layers: offset counts + main kernel + partial-slab reduce")
-            work["spconv_wgrad_main"] = dict(wg, scope="dominant kernel only (rocprofv3: spconv_wgrad*_kernel)")
+            # algorithmic bytes: features in and out once (bf16 storage under bf16 autocast), 8 B per rulebook pair,
+            # the fp32 weights once
+            fb = 2 if self.amp else 4
+            byts = sum((ni * ci + no * co) * fb + P * 8 + 27 * ci * co * 4 for P, ci, co, ni, no in layers)
+            # under bf16 autocast forward, data gradient AND weight gradient run on the bf16 MFMA (the 5-channel first layer
+            # excepted); in fp32 all three use the fp32-input MFMA.  The binding roof is the lower of the two ceilings
+            # min(MFMA peak, intensity x HBM peak): with bf16 MFMAs these ops sit on the HBM side of the ridge.
+            peak, note = MFMA_PEAK_BF16 if self.amp else MFMA_PEAK_F32
+            bound = "mfma" if flops / byts * HBM_PEAK_GBS * 1e9 > peak * 1e12 else "hbm"
+            sp_work = dict(bound=bound, flops=flops, bytes=byts, unit_peak=peak, peak_note=note)
+            work["spconv_fwd"] = dict(sp_work, scope="21 gather-GEMM launches (all sparse conv layers of the step)")
+            work["spconv_bwd"] = dict(sp_work, scope="dgrad: 20 gather-GEMM launches")
+            work["spconv_wgrad"] = dict(sp_work, scope="whole op x 21 layers: main kernel + partial-slab reduce (+ offset counts on the fp32 path)")
+            work["spconv_wgrad_main"] = dict(sp_work, scope="dominant kernel only (rocprofv3: spconv_wgrad*_kernel)")
             # rulebooks actually built per step (SubM ones are shared per stage): N_in*16 + hash table 2*N*8 + P*8
             uniq = {(P, ni, no) for P, _, _, ni, no in layers}
             work["rulebook"] = dict(bound="hbm", bytes=sum(ni * 16 + 2 * max(ni, no) * 8 + P * 8 for P, ni, no in uniq),
@@ -637,6 +641,10 @@ def main():
                 ach = w["bytes"] / sec_per_step / 1e9
                 r.update(achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                          algorithmic_bytes_per_step=int(w["bytes"]))
+                if "flops" in w:  # an op with matrix work on the HBM side of the ridge: the other ceiling, for reference
+                    tf = w["flops"] / sec_per_step / 1e12
+                    r.update(algorithmic_flops_per_step=w["flops"], tflops=round(tf, 2), mfma_frac=round(tf / w["unit_peak"], 4),
+                             peak_note=w.get("peak_note", ""))
             else:
                 ach = w["flops"] / sec_per_step / 1e12
                 r.update(achieved=round(ach, 2), peak=w["unit_peak"], unit="TFLOP/s", frac=round(ach / w["unit_peak"], 4),

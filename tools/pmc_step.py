@@ -19,7 +19,7 @@ FAMILIES = [
     ("attn (all)", lambda n: "attn_" in n),
     ("lift_splat_fwd", lambda n: "lift_splat_fwd" in n),
     ("lift_splat_bwd", lambda n: "lift_splat_bwd" in n),
-    ("rulebook", lambda n: "sparse_" in n or "subm_" in n or "rulebook" in n),
+    ("rulebook", lambda n: "sparse_" in n or "subm_" in n or "row_mask" in n or "words_" in n or "blocks_scan" in n or "fill_pair" in n),
 ]
 
 
@@ -37,16 +37,33 @@ def per_family(path, counter):
     return tot, cnt
 
 
+# bench.py op name -> kernel family above (ops whose launches can be told apart by kernel name)
+BENCH_OPS = {"spconv_wgrad": ["spconv_wgrad", "wgrad_reduce + offset counts"], "lift_splat_fwd": ["lift_splat_fwd"],
+             "lift_splat_bwd": ["lift_splat_bwd"], "rulebook": ["rulebook"]}
+
+
 def main(fetch_csv, write_csv, steps):
     steps = float(steps)
     f, fc = per_family(fetch_csv, "FETCH_SIZE")
     w, _ = per_family(write_csv, "WRITE_SIZE")
-    out = {}
-    for fam, _ in FAMILIES:
-        if fc.get(fam):
-            out[fam] = dict(launches_per_step=round(fc[fam] / steps, 2), fetch_bytes_raw_per_step=round(f[fam] / steps, 1),
-                            write_bytes_per_step=round(w.get(fam, 0.0) / steps, 1))
-    print(json.dumps(out, indent=1))
+    fam = {}
+    for name, _ in FAMILIES:
+        if fc.get(name):
+            fam[name] = dict(launches_per_step=round(fc[name] / steps, 2), fetch_bytes_raw_per_step=round(f[name] / steps, 1),
+                             write_bytes_per_step=round(w.get(name, 0.0) / steps, 1))
+    kernels = {}
+    for op, names in BENCH_OPS.items():
+        got = [fam[n] for n in names if n in fam]
+        if got:
+            fetch = sum(g["fetch_bytes_raw_per_step"] for g in got)
+            write = sum(g["write_bytes_per_step"] for g in got)
+            kernels[op] = dict(fetch_bytes_raw=fetch, write_bytes=write, hbm_bytes=fetch + write,
+                               hbm_bytes_note="per training step; FETCH_SIZE raw (gather kernels: uncalibrated lower bound, "
+                                              "MI355X_MICROARCH.md) + WRITE_SIZE")
+    print(json.dumps({"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two separate --kernel-trace passes of "
+                                 "bench.py --workload full (batch 4, 40k points), summed per kernel family and divided by the "
+                                 "%d steps of the run (tools/pmc_step.py)" % int(steps),
+                      "_units": "counter values x 1024 B", "kernels": kernels, "full_step": fam}, indent=1))
 
 
 if __name__ == "__main__":
