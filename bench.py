@@ -206,7 +206,8 @@ class _ModelWorkload:
             # conv / linear weights held in bf16 (what the kernels consume), fp32 masters in the optimizer: same arithmetic
             # as autocast without ~320 per-step cast launches; DDP then reduces bf16 gradients for these layers
             from bevfusion_amd.amp import MasterWeightAdamW
-            self.opt = MasterWeightAdamW(self.model, lr=2e-4, weight_decay=0.01, max_grad_norm=35.0,
+            exclude = ("pts_middle_encoder", "heatmap_head") + (() if self.vt_bf16 else ("view_transform",))  # fp32 island: fp32 weights
+            self.opt = MasterWeightAdamW(self.model, lr=2e-4, weight_decay=0.01, max_grad_norm=35.0, exclude=exclude,
                                          capturable=self.use_graph)  # before DDP: dtypes fixed
         else:
             self.opt = torch.optim.AdamW(self.model.parameters(), lr=2e-4, weight_decay=0.01, fused=True,
