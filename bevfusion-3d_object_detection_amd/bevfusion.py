@@ -337,10 +337,11 @@ def nuscenes_config(camera=True, lidar=True):
 
 
 def surrogate_loss(outs, depth_loss=0.0):
-    """Stand-in for BEVFusionHead.loss (BF/bevfusion_head.py:676-796), which needs the Hungarian assigner
-    (CPU + scipy in the reference, BF/utils.py:241-284) and GT boxes: a Gaussian-focal style term on the
-    dense heat-map plus L1 terms on every regression head, so that backward reaches every parameter the
-    real loss reaches.  Used by bench.py only; not a training objective."""
+    """A ground-truth-free scalar over every head output (a Gaussian-focal style term on the dense heat-map plus L1 terms on
+    every regression head), so that backward reaches every parameter the real loss reaches.  Used only by the smoke-sized
+    plumbing tests in tests/test_model_gpu.py that have no GT boxes; bench.py and the parity tests use the real
+    `BEVFusion.loss` -> `BEVFusionHead.loss` (BF/bevfusion_head.py:676-796, Hungarian targets on the device).  Not a
+    training objective."""
     res = outs[0][0]
     hm = res["dense_heatmap"].float().sigmoid().clamp(1e-4, 1 - 1e-4)
     loss = -(torch.log(1 - hm) * hm.pow(2)).mean()
