@@ -102,45 +102,54 @@ __device__ __forceinline__ const bf16_t *piece_src(const bf16_t *x, const ConvGe
 
 // ---- epilogue of the implicit-GEMM kernel: (optional) BatchNorm statistics of the raw accumulators, then
 // accumulators -> LDS [BM][BN] -> 16-byte coalesced stores.  M rows, Kout columns, row pitch ldy.
-template <int WM, int WN, bool OUT_F32>
-__device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[2][WN], unsigned char *smem, int tm, long long m0, int n0,
+template <int WGM, int WGN, int MI, int NI, bool OUT_F32>
+__device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned char *smem, int tm, long long m0, int n0,
                                                long long M, int Kout, int ldy, const float *__restrict__ bias,
                                                void *__restrict__ y, float *__restrict__ stat_partial) {
-  constexpr int NTHREADS = WM * 128;
-  constexpr int BN = WN * 64, BM = WM * 64;
+  constexpr int NTHREADS = WGM * WGN * 64;
+  constexpr int BN = WGN * NI * 32, BM = WGM * MI * 32;
+  constexpr int PR = BM / 128;   // statistics partial rows of this tile (one per 128 pixels)
+  constexpr int G = WGM / PR;    // wave rows that make up one partial row
+  static_assert(BM % 128 == 0 && G * PR == WGM, "tile rows must be whole 128-row statistic groups");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / WGN, wn = w % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
   __syncthreads();  // every wave is done with the staging buffers: reuse them for the epilogue
 
   // ---- BatchNorm statistics of the raw accumulators (rows beyond M are exact zeros): per-column sum / sum of squares,
   //      one partial row per 128 rows of the tile
   if (stat_partial) {
-    float *sred = (float *)(smem);  // [WM][BN][2]
+    float *sred = (float *)(smem);  // [WGM][BN][2]
 #pragma unroll
-    for (int ni = 0; ni < WN; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       float s = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { float v = acc[mi][ni][r]; s += v; s2 += v * v; }
       s += __shfl_xor(s, 32);
       s2 += __shfl_xor(s2, 32);
       if (lh == 0) {
-        int col = wn * (WN * 32) + ni * 32 + l31;
+        int col = wn * (NI * 32) + ni * 32 + l31;
         sred[(wm * BN + col) * 2 + 0] = s;
         sred[(wm * BN + col) * 2 + 1] = s2;
       }
     }
     __syncthreads();
     const int total_rows = (int)((M + 127) / 128);
-    for (int e = tid; e < (WM / 2) * BN; e += NTHREADS) {
-      const int half = e / BN, col = e - half * BN;
-      const int prow = tm * (WM / 2) + half;
+    for (int e = tid; e < PR * BN; e += NTHREADS) {
+      const int pr = e / BN, col = e - pr * BN;
+      const int prow = tm * PR + pr;
       if (n0 + col < Kout && prow < total_rows) {
-        const float *p0 = sred + ((half * 2) * BN + col) * 2, *p1 = sred + ((half * 2 + 1) * BN + col) * 2;
-        stat_partial[((size_t)prow * 2 + 0) * Kout + n0 + col] = p0[0] + p1[0];
-        stat_partial[((size_t)prow * 2 + 1) * Kout + n0 + col] = p0[1] + p1[1];
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const float *q = sred + ((pr * G + gi) * BN + col) * 2;
+          t0 += q[0];
+          t1 += q[1];
+        }
+        stat_partial[((size_t)prow * 2 + 0) * Kout + n0 + col] = t0;
+        stat_partial[((size_t)prow * 2 + 1) * Kout + n0 + col] = t1;
       }
     }
     __syncthreads();
@@ -150,14 +159,14 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[2][WN], unsigned ch
   constexpr int ESZ = OUT_F32 ? 4 : 2;
   constexpr int ROWB = BN * ESZ;
 #pragma unroll
-  for (int ni = 0; ni < WN; ++ni) {
-    const int col = wn * (WN * 32) + ni * 32 + l31;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = wn * (NI * 32) + ni * 32 + l31;
     const float bv = (bias && n0 + col < Kout) ? bias[n0 + col] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = wm * (MI * 32) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const float v = acc[mi][ni][r] + bv;
         if (OUT_F32) *(float *)(smem + row * ROWB + col * 4) = v;
         else *(bf16_t *)(smem + row * ROWB + col * 2) = (bf16_t)rne_bf16(v);
@@ -183,27 +192,27 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[2][WN], unsigned ch
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
-// Tile (WM * 64) rows x (WN * 64) columns, WM * 2 waves (wave tile 64 x WN*32), a ring of STAGES LDS stages of one K step
-// (64 bf16) each.  Rows are 128 bytes (8 pieces); piece c of row r sits at position c ^ ((r >> 1) & 7): the 16 rows a
-// ds_read_b128 lane group touches land on 16 distinct 16-byte slots.
-//   <2, WN, 2>: 128-row tiles, 256 threads, two stages, two workgroups per CU (small problems, narrow outputs)
-//   <4, 2, 3> : 256 x 128 tiles, 512 threads, three stages = TWO K steps (96 KB) in flight per CU under the MFMAs of the
-//               third: at ~64 B/clk/CU of operand traffic and ~1500 cycles of loaded L2 latency that is what it takes to keep
-//               the DMA queue from draining (Little's law); the waits are counted (`vmcnt(GL)` leaves the next stage's GL
-//               DMA instructions in flight) and the barrier is the raw s_barrier, which does not drain them.
+// Tile BM = WGM*MI*32 rows x BN = WGN*NI*32 columns, WGM x WGN waves with (MI*32) x (NI*32) wave tiles of 32x32x16 MFMAs, a
+// ring of STAGES LDS stages of one K step (64 bf16) each.  Rows are 128 bytes (8 pieces); piece c of row r sits at position
+// c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 lane group touches land on 16 distinct 16-byte slots.
+//   <2, 2, 2, NI, 2>: 128 x (64 | 128) tiles, 256 threads, two stages, two workgroups per CU (small problems, narrow outputs)
+//   <2, 4, 4, 2, 2> : 256 x 256 tiles, 512 threads (8 waves as 2 x 4, wave tile 128 x 64), two stages of 64 KB: half the
+//                     operand bytes per flop of the 128 x 128 tile (the L2 -> LDS fill rate of a CU, ~40-70 GB/s, is what the
+//                     small tile runs into) and 3/4 of its LDS fragment reads per MFMA; for wide outputs with enough tiles
+//   <4, 2, 2, 2, 3> : 256 x 128 tiles with 64 x 64 wave tiles and a three-stage ring -- measured, no gain (BFHIP_CONV_BIG_TILES)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM, int WN, int STAGES, bool OUT_F32, bool TR>
-__global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt,
-                                                                 const float *__restrict__ bias, void *__restrict__ y,
-                                                                 float *__restrict__ stat_partial, ConvGeom g, int tiles_m,
-                                                                 int tiles_n) {
-  constexpr int NTHREADS = WM * 128, NWAVES = WM * 2;
-  constexpr int BN = WN * 64, BM = WM * 64, BK = 64;
+template <int WGM, int WGN, int MI, int NI, int STAGES, bool OUT_F32, bool TR>
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_igemm_kernel(
+    const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt, const float *__restrict__ bias, void *__restrict__ y,
+    float *__restrict__ stat_partial, ConvGeom g, int tiles_m, int tiles_n) {
+  constexpr int NWAVES = WGM * WGN, NTHREADS = NWAVES * 64;
+  constexpr int BN = WGN * NI * 32, BM = WGM * MI * 32, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, S_BYTES = A_BYTES + B_BYTES;
-  constexpr int NB = (BN / 8) / NWAVES;  // B DMA instructions per wave and stage (8 rows each)
-  constexpr int GL = 4 + NB;             // DMA instructions per wave and stage
-  static_assert(NB >= 1 && NB * 8 * NWAVES == BN, "B tile must split into whole DMA instructions");
+  constexpr int NA = (BM / 8) / NWAVES;  // A DMA instructions per wave and stage (8 rows each)
+  constexpr int NB = (BN / 8) / NWAVES;  // B DMA instructions per wave and stage
+  constexpr int GL = NA + NB;            // DMA instructions per wave and stage
+  static_assert(NA >= 1 && NA * 8 * NWAVES == BM && NB >= 1 && NB * 8 * NWAVES == BN, "tiles must split into whole DMA instructions");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned *taps = (unsigned *)(smem + STAGES * S_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -219,13 +228,13 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
     taps[q] = ((unsigned)(kh * g.dil) << 24) | ((unsigned)(kw * g.dil) << 16) | (unsigned)ci;
   }
 
-  // ---- per-lane staging state: 4 A rows (one per DMA instruction) and NB B rows; every wave stages 32 A rows
+  // ---- per-lane staging state: NA A rows (one per DMA instruction) and NB B rows; every wave stages NA*8 A rows
   const int lrow = lane >> 3, lpos = lane & 7;
-  int nb[4], hb[4], wb[4];
-  bool rok[4];
+  int nb[NA], hb[NA], wb[NA];
+  bool rok[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    long long m = m0 + w * 32 + i * 8 + lrow;
+  for (int i = 0; i < NA; ++i) {
+    long long m = m0 + w * (NA * 8) + i * 8 + lrow;
     rok[i] = m < g.M;
     long long mm = rok[i] ? m : 0;
     int n = (int)(mm / ((long long)g.OH * g.OW));
@@ -246,11 +255,11 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
   const int nt = (g.nq + 7) >> 3;
   const bf16_t *zsrc = zero_src();
   auto stage = [&](int t, int buf) {  // exactly GL DMA instructions per wave (the counted waits rely on it)
-    unsigned char *dA = smem + buf * S_BYTES + (w * 32) * 128;
+    unsigned char *dA = smem + buf * S_BYTES + (w * (NA * 8)) * 128;
     unsigned char *dB = smem + buf * S_BYTES + A_BYTES + (w * (NB * 8)) * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int swz = (i * 4 + (lane >> 4)) & 7;  // ((row >> 1) & 7) of row = w*32 + i*8 + lrow
+    for (int i = 0; i < NA; ++i) {
+      const int swz = ((w * (NA * 8) + i * 8 + lrow) >> 1) & 7;
       const int q = t * 8 + (lpos ^ swz);
       const bf16_t *src = q < g.nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q], zsrc) : zsrc;
       glds16(src, dA + i * 1024);
@@ -264,17 +273,17 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
     }
   };
 
-  f32x16 acc[2][WN];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < WN; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / WGN, wn = w % WGN;
   const int l31 = lane & 31, lh = lane >> 5, rswz = (lane >> 1) & 7;  // ((row >> 1) & 7) of row = 32*j + l31
-  const int aoff = (wm * 64 + l31) * 128, boff = A_BYTES + (wn * (WN * 32) + l31) * 128;
+  const int aoff = (wm * (MI * 32) + l31) * 128, boff = A_BYTES + (wn * (NI * 32) + l31) * 128;
 
 #pragma unroll
   for (int s0 = 0; s0 < STAGES - 1; ++s0)
@@ -292,20 +301,20 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_igemm_kernel(const bf16_t *_
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int pos = ((2 * ks + lh) ^ rswz) << 4;
-      bf16x8 a[2], b[WN];
+      bf16x8 a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8 *)(pA + mi * 32 * 128 + pos);
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8 *)(pA + mi * 32 * 128 + pos);
 #pragma unroll
-      for (int ni = 0; ni < WN; ++ni) b[ni] = *(const bf16x8 *)(pB + ni * 32 * 128 + pos);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8 *)(pB + ni * 32 * 128 + pos);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
     buf = buf + 1 == STAGES ? 0 : buf + 1;
     nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
   }
-  igemm_epilogue<WM, WN, OUT_F32>(acc, smem, tm, m0, n0, g.M, g.Kout, g.ldy, bias, y, stat_partial);
+  igemm_epilogue<WGM, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, g.M, g.Kout, g.ldy, bias, y, stat_partial);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -633,7 +642,7 @@ bool geom_ok(int N, int H, int W, int C, int KH, int KW, int stride, int pad, in
          (KH - 1) * dil < 256 && (KW - 1) * dil < 256 && (long long)KH * KW * C / 8 <= 8192;
 }
 
-size_t igemm_lds_bytes(int WM, int WN, int stages, int nq) { return (size_t)stages * (WM + WN) * 64 * 128 + (size_t)nq * 4; }
+size_t igemm_lds_bytes(int BM, int BN, int stages, int nq) { return (size_t)stages * (BM + BN) * 128 + (size_t)nq * 4; }
 
 
 // ---- internal entry points for spconv.hip (declared in common.h)
@@ -697,32 +706,38 @@ BFHIP_EXPORT int bfhip_conv2d_stat_rows(int N, int OH, int OW) { return ceil_div
 
 static int launch_igemm(const void *x, const void *wt, const float *bias, void *y, float *stat_partial, ConvGeom g, int out_f32,
                         hipStream_t s, const char *what) {
-  const int WN = g.Kout > 64 ? 2 : 1;
-  // 256 x 128 tiles with a three-stage ring (two K steps of DMA in flight, counted vmcnt, raw s_barrier) were measured
-  // against the 128-row tiles below on the 180 x 180 BEV layers: 0.301 vs 0.296 ms (336 -> 256), 0.072 vs 0.069 ms
-  // (128 -> 128) -- no gain: at a 64 x 64 wave tile the LDS is ~87 % busy at the MFMA peak either way (128 KB of fragment
-  // reads + 48 KB of DMA writes per K step and CU), so deeper prefetch has nothing to expose.  Opt-in for experiments only.
+  // tile shapes (see conv_igemm_kernel): 0 = 128 x 64, 1 = 128 x 128, 2 = 256 x 256 (bf16 output, wide GEMMs with at least
+  // ~1.5 tiles per CU), 3 = 256 x 128 with 64 x 64 wave tiles and three stages (experiment switch only)
   static const int force_big = getenv("BFHIP_CONV_BIG_TILES") ? 1 : 0;
-  const bool big = WN == 2 && force_big && ceil_div(g.M, 256) * ceil_div(g.Kout, 128) >= 192;
-  const int WM = big ? 4 : 2, stages = big ? 3 : 2;
-  const int tiles_m = ceil_div(g.M, WM * 64), tiles_n = ceil_div(g.Kout, WN * 64);
-  const size_t lds = igemm_lds_bytes(WM, WN, stages, g.nq);
+  // BFHIP_CONV_TILE256: 0 = never, 1 = by the rule below, 2 = whenever the output is bf16 and wider than 128 (tests)
+  static const int tile256 = [] { const char *e = getenv("BFHIP_CONV_TILE256"); return e ? atoi(e) : 1; }();
+  static const int tile256_min = [] { const char *e = getenv("BFHIP_CONV_TILE256_MIN"); return e ? atoi(e) : 384; }();
+  int shape = g.Kout > 64 ? 1 : 0;
+  const long long t256 = (long long)ceil_div(g.M, 256) * ceil_div(g.Kout, 256);
+  // enough tiles for the 256 one-workgroup CUs, and at most 1/8 of the 256-wide column tiles wasted
+  const bool fits256 = t256 >= tile256_min && (long long)ceil_div(g.Kout, 256) * 256 * 8 <= (long long)g.Kout * 9;
+  if (tile256 && !out_f32 && g.Kout > 128 && (fits256 || tile256 == 2)) shape = 2;
+  else if (shape == 1 && force_big && ceil_div(g.M, 256) * ceil_div(g.Kout, 128) >= 192) shape = 3;
+  const int BM = shape >= 2 ? 256 : 128, BN = shape == 2 ? 256 : (shape == 0 ? 64 : 128), stages = shape == 3 ? 3 : 2;
+  const int tiles_m = ceil_div(g.M, BM), tiles_n = ceil_div(g.Kout, BN);
+  const size_t lds = igemm_lds_bytes(BM, BN, stages, g.nq);
   dim3 grid((unsigned)((long long)tiles_m * tiles_n));
-#define BFHIP_IG(WMV, WNV, ST, F32, TRV)                                                                                \
+#define BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, TRV)                                                                    \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<WMV, WNV, ST, F32, TRV>,                                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, ST == 3 ? 160 * 1024 : 80 * 1024);         \
+      (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<WGMV, WGNV, MIV, NIV, ST, F32, TRV>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (WGMV * WGNV > 4) ? 159 * 1024 : 80 * 1024); \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_igemm_kernel<WMV, WNV, ST, F32, TRV>), grid, dim3(WMV * 128), lds, s, (const bf16_t *)x,  \
-                       (const bf16_t *)wt, bias, y, stat_partial, g, tiles_m, tiles_n);                                \
+    hipLaunchKernelGGL((conv_igemm_kernel<WGMV, WGNV, MIV, NIV, ST, F32, TRV>), grid, dim3(WGMV * WGNV * 64), lds, s,   \
+                       (const bf16_t *)x, (const bf16_t *)wt, bias, y, stat_partial, g, tiles_m, tiles_n);             \
   } while (0)
-#define BFHIP_IG2(WMV, WNV, ST, F32) do { if (g.transposed) BFHIP_IG(WMV, WNV, ST, F32, true); else BFHIP_IG(WMV, WNV, ST, F32, false); } while (0)
-  if (big) { if (out_f32) BFHIP_IG2(4, 2, 3, true); else BFHIP_IG2(4, 2, 3, false); }
-  else if (WN == 2) { if (out_f32) BFHIP_IG2(2, 2, 2, true); else BFHIP_IG2(2, 2, 2, false); }
-  else { if (out_f32) BFHIP_IG2(2, 1, 2, true); else BFHIP_IG2(2, 1, 2, false); }
+#define BFHIP_IG2(WGMV, WGNV, MIV, NIV, ST, F32) do { if (g.transposed) BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, true); else BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, false); } while (0)
+  if (shape == 2) BFHIP_IG2(2, 4, 4, 2, 2, false);
+  else if (shape == 3) { if (out_f32) BFHIP_IG2(4, 2, 2, 2, 3, true); else BFHIP_IG2(4, 2, 2, 2, 3, false); }
+  else if (shape == 1) { if (out_f32) BFHIP_IG2(2, 2, 2, 2, 2, true); else BFHIP_IG2(2, 2, 2, 2, 2, false); }
+  else { if (out_f32) BFHIP_IG2(2, 2, 2, 1, 2, true); else BFHIP_IG2(2, 2, 2, 1, 2, false); }
 #undef BFHIP_IG2
 #undef BFHIP_IG
   return check_launch(what);

@@ -28,7 +28,9 @@ GEOMS = [(2, 45, 52, 336, 256, 3, 1, 1, 1, False),   # ConvFuser (BF/bevfusion_h
          (2, 33, 47, 8, 32, 5, 4, 2, 1, True),       # dtransform 5x5 stride 4, 8 input channels
          (1, 20, 24, 64, 64, 3, 1, 2, 2, False),     # dilation 2
          (2, 32, 88, 768, 256, 1, 1, 0, 1, False),   # LSS-FPN lateral 1x1
-         (1, 7, 9, 16, 24, 3, 1, 1, 1, False)]       # a single partial tile
+         (1, 7, 9, 16, 24, 3, 1, 1, 1, False),       # a single partial tile
+         (2, 223, 225, 16, 256, 3, 1, 1, 1, True),   # >= 384 row tiles x 256 columns: forward takes the 256 x 256 tile kernel
+         (2, 223, 225, 256, 16, 3, 1, 1, 1, False)]  # ... and here the data gradient does (its GEMM columns are Cin = 256)
 
 
 def _bf16_round(a):
