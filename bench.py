@@ -45,6 +45,11 @@ import torch  # noqa: E402
 MIOPEN_FIND = os.environ.get("BENCH_MIOPEN_FIND", "0") == "1"
 # gradient exchange between ranks: "flat" = one all-reduce per dtype after the backward (default), "ddp" = torch DDP buckets
 GRAD_SYNC = os.environ.get("BENCH_GRAD_SYNC", "flat")
+# library profiler level: 1 = sparse / lift-splat / voxel ops, 2 = also the dense ops (conv2d_*, bn2d_*: ~280 more event pairs
+# per training step)
+PROFILE_LEVEL = int(os.environ.get("BENCH_PROFILE_LEVEL", "2"))
+DENSE_EVERY = max(1, int(os.environ.get("BENCH_PROFILE_DENSE_EVERY", "10")))
+DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
 # dense matrix-core peaks (MI355X_MICROARCH.md): bf16 v_mfma_f32_32x32x16_bf16 / fp32-input v_mfma_f32_16x16x4_f32
 MFMA_PEAK_BF16 = (2500.0, "bf16 MFMA dense peak ~2500 TFLOP/s (v_mfma_f32_*_bf16)")
@@ -349,6 +354,58 @@ class _ModelWorkload:
                                           scope="fused outer product + gathers + bev_pool forward, one launch")
             work["lift_splat_bwd"] = dict(bound="hbm", bytes=P * D * 4 + P * C * 4 + P * D * 4 + self.m * C * 4 + P * D * 4 + P * C * 4,
                                           scope="fused backward, one launch")
+        if PROFILE_LEVEL >= 2:
+            work.update(self._dense_work())
+        return work
+
+    def _dense_work(self):
+        """Algorithmic flops / bytes of the hand-written dense ops (csrc/conv2d.hip, csrc/bn2d.hip) of one step, from one
+        instrumented forward: every call's shape is recorded at the Python entry of the op."""
+        from bevfusion_amd import bn2d as b2, conv2d as c2
+        convs, bns = [], []
+        orig_c, orig_b = c2._Conv2dFunction.forward, b2._apply
+
+        def spy_c(ctx, x, weight, bias, stride, pad, dil, emit_stats):
+            N, Cin, H, W = x.shape
+            Cout, _, KH, KW = weight.shape
+            OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+            OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+            convs.append((N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin))
+            return orig_c(ctx, x, weight, bias, stride, pad, dil, emit_stats)
+
+        def spy_b(x, residual, *a, **k):
+            if x.is_cuda and x.dim() == 4:
+                has_partial = (len(a) > 7 and a[7] is not None) or k.get("partial") is not None
+                bns.append((x.numel() * x.element_size(), residual is not None, has_partial))
+            return orig_b(x, residual, *a, **k)
+
+        c2._Conv2dFunction.forward, b2._apply = staticmethod(spy_c), spy_b
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+                self.step_model(self.inputs, None, self.gts)
+        finally:
+            c2._Conv2dFunction.forward, b2._apply = staticmethod(orig_c), orig_b
+        work = {}
+        peak, note = MFMA_PEAK_BF16
+
+        def conv_entry(sel, scope):
+            rows = [c for c in convs if sel(c)]
+            fl = sum(2.0 * m * k * co for m, k, co, _, _ in rows)
+            by = sum((xin + m * co + k * co) * 2 for m, k, co, _, xin in rows)
+            bound = "mfma" if fl / max(by, 1) * HBM_PEAK_GBS * 1e9 > peak * 1e12 else "hbm"
+            return dict(bound=bound, flops=fl, bytes=by, unit_peak=peak, peak_note=note, scope="%d launches per step: %s" % (len(rows), scope))
+
+        if convs:
+            work["conv2d_fwd"] = conv_entry(lambda c: True, "implicit-GEMM forward of the BEV / view-transform / LSS-FPN convolutions (csrc/conv2d.hip)")
+            work["conv2d_dgrad"] = conv_entry(lambda c: c[3], "weight transpose + implicit GEMM in transposed-gather mode")
+            work["conv2d_wgrad"] = conv_entry(lambda c: True, "pixel-major LDS tiles, transposing LDS reads, split pixel range + fixed-order slab sum")
+        if bns:
+            # forward: statistics pass (unless the producing conv accumulated them) + apply (read, write) [+ residual read];
+            # backward: reduce (dy, x) + apply (dy, x -> dx) [+ y read and d_residual write for residual layers]
+            work["bn2d_fwd"] = dict(bound="hbm", bytes=sum(b * ((2 if p else 3) + (1 if r else 0)) for b, r, p in bns),
+                                    scope="%d BatchNorm(+residual)(+ReLU) layers per step: statistics, finalize, apply" % len(bns))
+            work["bn2d_bwd"] = dict(bound="hbm", bytes=sum(b * (5 + (2 if r else 0)) for b, r, p in bns),
+                                    scope="%d layers per step: reduce, finalize, apply" % len(bns))
         return work
 
     def cpu_baseline(self, frames):
@@ -581,12 +638,19 @@ def main():
     barrier()
     graphed = bool(getattr(wl, "use_graph", False))
     if not cpu_mode and not graphed:
-        _lib.profile_enable(True)
+        _lib.profile_enable(PROFILE_LEVEL)
         for op in _lib.OPS:
             _lib.profile_read(op, reset=True)
     t0 = time.perf_counter()
     last_loss = None
-    for _ in range(args.steps):
+    dense_steps = 0
+    for i in range(args.steps):
+        if not cpu_mode and not graphed and PROFILE_LEVEL >= 2:
+            # the dense ops add ~280 event pairs (1.8 ms of host time) to a step: they are timed on every DENSE_EVERY-th step of
+            # the timed region only, the sparse / lift-splat ops on all of them
+            dense = i % DENSE_EVERY == 0
+            _lib.profile_enable(2 if dense else 1)
+            dense_steps += dense
         last_loss = wl.step()
     barrier()
     dt = time.perf_counter() - t0
@@ -597,11 +661,12 @@ def main():
         # come from a few EAGER steps of the same workload after the timed region (same kernels, same sizes)
         prof_steps = 5
         torch.cuda.synchronize()
-        _lib.profile_enable(True)
+        _lib.profile_enable(PROFILE_LEVEL)
         for op in _lib.OPS:
             _lib.profile_read(op, reset=True)
         for _ in range(prof_steps):
             wl._eager_step()
+        dense_steps = prof_steps
         torch.cuda.synchronize()
     if not cpu_mode:
         _lib.profile_enable(False)
@@ -614,10 +679,12 @@ def main():
     value = frames / dt
 
     if rank == 0:
-        ops = {op: {"ms_per_step": round(ms / prof_steps, 4), "launches_per_step": cnt / prof_steps}
+        ops = {op: {"ms_per_step": round(ms / (max(dense_steps, 1) if op in DENSE_OPS else prof_steps), 4),
+                    "launches_per_step": cnt / (max(dense_steps, 1) if op in DENSE_OPS else prof_steps)}
                for op, (ms, cnt) in prof.items() if cnt}
         # dominant hand-written op of the step = the one with the largest accumulated event time
-        dom = max((op for op in work if prof.get(op, (0, 0))[1] and op != "spconv_wgrad_main"), key=lambda o: prof[o][0], default=None)
+        dom = max((op for op in work if prof.get(op, (0, 0))[1] and op != "spconv_wgrad_main"),
+                  key=lambda o: prof[o][0] / (max(dense_steps, 1) if o in DENSE_OPS else prof_steps), default=None)
         # HBM traffic: PMC counters cannot be read from inside this process; the value is the rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE measurement committed under profiles/ (same batch-4 sizes), tagged with its source
         pmc, pmc_src = {}, None
@@ -629,12 +696,17 @@ def main():
             except (OSError, KeyError, ValueError):
                 continue
 
+        def steps_of(op):  # timed steps the op's events cover
+            return max(dense_steps, 1) if op in DENSE_OPS else prof_steps
+
         def roof_of(op):
             ms, cnt = prof[op]
             w = work[op]
-            sec_per_step = ms * 1e-3 / prof_steps
+            n_steps = steps_of(op)
+            sec_per_step = ms * 1e-3 / n_steps
             traffic = int(pmc[op]["hbm_bytes"]) if (op in pmc and args.batch == 4 and args.points == 40000) else None
-            r = {"kernel": op, "bound": w["bound"], "ms_per_step": round(ms / prof_steps, 5), "launches_per_step": cnt / prof_steps,
+            r = {"kernel": op, "bound": w["bound"], "ms_per_step": round(ms / n_steps, 5), "launches_per_step": cnt / n_steps,
+                 "timed_steps_sampled": n_steps,
                  "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None}
             if "scope" in w:
                 r["scope"] = w["scope"]

@@ -599,6 +599,8 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
   BFHIP_REQUIRE((long long)pl.grid.y * (1 + pl.ng) <= kSlabInts, "bn2d_fwd: too many column tiles");
   Tree tr{cnt, pl.gp, pl.nblk, pl.ng};
   FwdFin fin{M, m_dev, C, eps, momentum, gamma, beta, stats, running_mean, running_var};
+  ProfScope ps;
+  prof_begin(BFHIP_OP_BN2D_FWD, s, &ps);
   if (dtype == 1)
     hipLaunchKernelGGL(bn2d_stats_kernel<bf16_t>, pl.grid, dim3(256), 0, s, (const bf16_t *)x, M, C, pl.mp, pl.partial, tr, fin);
   else
@@ -606,6 +608,7 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
   if (!cnt) hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, pl.partial, pl.nblk, fin);
   if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, pl.mp, pl.grid, relu, y, s);
   else run_fwd<float>(x, residual, stats, M, C, pl.mp, pl.grid, relu, y, s);
+  prof_end(&ps);
   return check_launch("bn2d_fwd");
 }
 
@@ -621,9 +624,12 @@ BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, co
   dim3 grid;
   Map mp = make_map(M, C, dtype, &grid);
   FwdFin fin{M, m_dev, C, eps, momentum, gamma, beta, stats, running_mean, running_var};
+  ProfScope ps;
+  prof_begin(BFHIP_OP_BN2D_FWD, s, &ps);
   hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, fin);
   if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
   else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
+  prof_end(&ps);
   return check_launch("bn2d_fwd_partials");
 }
 
@@ -645,6 +651,8 @@ BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, co
   BwdFin fin{M, m_dev, C, stats, dgb, pl.coef};
   // ReLU mask: from the saved output when one is given (residual layers), otherwise recomputed from x
   const int mask = !relu ? 0 : (y ? 2 : 1);
+  ProfScope ps;
+  prof_begin(BFHIP_OP_BN2D_BWD, s, &ps);
 #define BFHIP_BN2D_BWD(T, MASK) run_bwd<T, MASK>(dy, x, y, stats, M, C, pl.mp, pl.grid, pl.partial, pl.coef, tr, fin, dx, dres, s)
   if (dtype == 1) {
     if (mask == 0) BFHIP_BN2D_BWD(bf16_t, 0);
@@ -656,5 +664,6 @@ BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, co
     else BFHIP_BN2D_BWD(float, 2);
   }
 #undef BFHIP_BN2D_BWD
+  prof_end(&ps);
   return check_launch("bn2d_bwd");
 }

@@ -27,6 +27,7 @@ bool prof_enabled() { return g_prof_on != 0; }
 void prof_begin(int op, hipStream_t s, ProfScope *sc) {
   sc->active = false;
   if (!g_prof_on || op < 0 || op >= BFHIP_OP_COUNT) return;
+  if (op >= BFHIP_OP_CONV2D_FWD && g_prof_on < 2) return;  // dense ops: level 2 only
   if (hipEventCreate(&sc->a) != hipSuccess) return;
   if (hipEventCreate(&sc->b) != hipSuccess) { hipEventDestroy(sc->a); return; }
   hipEventRecord(sc->a, s);

@@ -763,7 +763,11 @@ BFHIP_EXPORT int bfhip_conv2d_fwd(const void *x, int ldx, const void *w, const f
   g.M = (long long)N * g.OH * g.OW;
   g.Kout = Cout; g.ldw = KH * KW * Cin; g.ldy = ldy;
   BFHIP_REQUIRE((long long)N * H * W * ldx < (1LL << 31), "conv2d_fwd: tensors of 2^31 elements or more are not supported");
-  return launch_igemm(x, w, bias, y, stat_partial, g, out_f32, (hipStream_t)stream_, "conv2d_fwd");
+  ProfScope ps;
+  prof_begin(BFHIP_OP_CONV2D_FWD, (hipStream_t)stream_, &ps);
+  const int rc = launch_igemm(x, w, bias, y, stat_partial, g, out_f32, (hipStream_t)stream_, "conv2d_fwd");
+  prof_end(&ps);
+  return rc;
 }
 
 BFHIP_EXPORT size_t bfhip_conv2d_dgrad_workspace_bytes(int Cin, int Cout, int KH, int KW) {
@@ -782,6 +786,8 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
   BFHIP_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)workspace % 16) == 0 && ldg % 8 == 0 && ldg >= Cout && ldx >= Cin,
                 "conv2d_dgrad: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
   const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  ProfScope ps;
+  prof_begin(BFHIP_OP_CONV2D_DGRAD, s, &ps);
   hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW), dim3(256), 0, s,
                      (const bf16_t *)w, (bf16_t *)workspace, Cout, KH * KW, Cin);
   ConvGeom g;
@@ -794,7 +800,9 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
   g.nq = KH * KW * Cout / 8;
   g.M = (long long)N * H * W;
   g.Kout = Cin; g.ldw = KH * KW * Cout; g.ldy = ldx;
-  return launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad");
+  const int rc = launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad");
+  prof_end(&ps);
+  return rc;
 }
 
 static int resident_blocks() {  // workgroups the chip holds at once (2 per CU: 66 KB of LDS each)
@@ -857,10 +865,13 @@ BFHIP_EXPORT int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int 
     (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2);
     attr_set = true;
   }
+  ProfScope ps;
+  prof_begin(BFHIP_OP_CONV2D_WGRAD, s, &ps);
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)wg.tiles_co * wg.tiles_k * wg.splits)), dim3(256), lds, s,
                      (const bf16_t *)x, (const bf16_t *)dy, (float *)workspace, wg);
   const long long total = (long long)Cout * KH * KW * Cin;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(total, 1024)), dim3(256), 0, s, (const float *)workspace, wg.splits,
                      total, dw, dw_bf16);
+  prof_end(&ps);
   return check_launch("conv2d_wgrad");
 }

@@ -54,7 +54,13 @@ extern "C" {
 #define BFHIP_OP_SPCONV_WGRAD 12 /* whole op: offset counts + main kernel + partial-slab reduce */
 #define BFHIP_OP_RASTER 13
 #define BFHIP_OP_SPCONV_WGRAD_MAIN 14 /* the dominant kernel alone (what rocprofv3 lists as spconv_wgrad64p_kernel) */
-#define BFHIP_OP_COUNT 16
+/* dense ops: recorded only at profile level 2 (bfhip_profile_enable(2)): ~280 scopes per training step */
+#define BFHIP_OP_CONV2D_FWD 15   /* bfhip_conv2d_fwd */
+#define BFHIP_OP_CONV2D_DGRAD 16 /* bfhip_conv2d_dgrad: weight transpose + implicit GEMM */
+#define BFHIP_OP_CONV2D_WGRAD 17 /* bfhip_conv2d_wgrad: main kernel + slab reduce */
+#define BFHIP_OP_BN2D_FWD 18     /* bfhip_bn2d_fwd / _fwd_partials: statistics, finalize, apply */
+#define BFHIP_OP_BN2D_BWD 19     /* bfhip_bn2d_bwd: reduce, finalize, apply */
+#define BFHIP_OP_COUNT 24
 
 int bfhip_abi_version(void);
 /* thread-local, valid until the next failing call on the same thread */

@@ -12,9 +12,15 @@ import sys
 
 FAMILIES = [
     ("spconv_wgrad", lambda n: "spconv_wgrad" in n),
-    ("wgrad_reduce + offset counts", lambda n: "wgrad_reduce" in n or "wgrad_offset_counts" in n),
+    ("wgrad_reduce + offset counts", lambda n: ("wgrad_reduce" in n and "conv_wgrad_reduce" not in n) or "wgrad_offset_counts" in n),
+    ("conv_wgrad_reduce (slab sum of the sparse bf16 and the dense weight gradients)", lambda n: "conv_wgrad_reduce" in n),
     ("spconv_gemm (fwd + dgrad)", lambda n: "spconv_gemm" in n),
-    ("bn2d (all six kernels)", lambda n: "bn2d_" in n),
+    ("bn2d backward (reduce, finalize, apply)", lambda n: "bn2d_bwd" in n or ("bn2d_finalize" in n and "BwdFin" in n)),
+    ("bn2d forward (stats, finalize, apply)", lambda n: "bn2d_" in n),
+    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: "conv_igemm_kernel" in n and n.rstrip(">").rstrip().endswith("true")),
+    ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n),
+    ("conv2d wgrad (main kernel)", lambda n: "conv_wgrad_kernel" in n),
+    ("conv weight transpose", lambda n: "conv_weight_transpose" in n),
     ("bn1d", lambda n: "bn1d_" in n),
     ("attn (all)", lambda n: "attn_" in n),
     ("lift_splat_fwd", lambda n: "lift_splat_fwd" in n),
@@ -39,7 +45,13 @@ def per_family(path, counter):
 
 # bench.py op name -> kernel family above (ops whose launches can be told apart by kernel name)
 BENCH_OPS = {"spconv_wgrad": ["spconv_wgrad", "wgrad_reduce + offset counts"], "lift_splat_fwd": ["lift_splat_fwd"],
-             "lift_splat_bwd": ["lift_splat_bwd"], "rulebook": ["rulebook"]}
+             "lift_splat_bwd": ["lift_splat_bwd"], "rulebook": ["rulebook"],
+             "bn2d_fwd": ["bn2d forward (stats, finalize, apply)"], "bn2d_bwd": ["bn2d backward (reduce, finalize, apply)"],
+             "conv2d_fwd": ["conv2d forward (conv_igemm)"],
+             "conv2d_dgrad": ["conv2d dgrad (conv_igemm, transposed gather)", "conv weight transpose"],
+             "conv2d_wgrad": ["conv2d wgrad (main kernel)"]}
+# 16-byte-per-lane streaming readers: FETCH_SIZE reports half their bytes on gfx950 (MI355X_MICROARCH.md) -> doubled
+STREAMING = {"bn2d_fwd", "bn2d_bwd"}
 
 
 def main(fetch_csv, write_csv, steps):
@@ -57,9 +69,14 @@ def main(fetch_csv, write_csv, steps):
         if got:
             fetch = sum(g["fetch_bytes_raw_per_step"] for g in got)
             write = sum(g["write_bytes_per_step"] for g in got)
-            kernels[op] = dict(fetch_bytes_raw=fetch, write_bytes=write, hbm_bytes=fetch + write,
-                               hbm_bytes_note="per training step; FETCH_SIZE raw (gather kernels: uncalibrated lower bound, "
-                                              "MI355X_MICROARCH.md) + WRITE_SIZE")
+            if op in STREAMING:
+                kernels[op] = dict(fetch_bytes_raw=fetch, write_bytes=write, hbm_bytes=2 * fetch + write,
+                                   hbm_bytes_note="per training step; 2 x FETCH_SIZE (wide streaming reads are tallied at half "
+                                                  "their bytes on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE")
+            else:
+                kernels[op] = dict(fetch_bytes_raw=fetch, write_bytes=write, hbm_bytes=fetch + write,
+                                   hbm_bytes_note="per training step; FETCH_SIZE raw (gather kernels: uncalibrated lower bound, "
+                                                  "MI355X_MICROARCH.md) + WRITE_SIZE")
     print(json.dumps({"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two separate --kernel-trace passes of "
                                  "bench.py --workload full (batch 4, 40k points), summed per kernel family and divided by the "
                                  "%d steps of the run (tools/pmc_step.py)" % int(steps),
