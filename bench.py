@@ -616,7 +616,9 @@ def main():
         work = {}
     elif issubclass(cls, _ModelWorkload):
         wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=world > 1 or force_ddp, local_rank=local_rank)
-        work = wl.collect_work()
+        # BENCH_NO_WORK=1 (counter passes under rocprofv3): no instrumented extra forward, so every kernel family runs exactly
+        # warm-up + steps times
+        work = {} if os.environ.get("BENCH_NO_WORK") == "1" else wl.collect_work()
     else:
         wl = cls(dev, args.batch, args.points, seed_base=100 * rank)
         work = {"bev_pool_fwd": dict(bound="hbm", bytes=wl.dominant_bytes())}

@@ -8,6 +8,7 @@ their bytes on gfx950 (MI355X_MICROARCH.md) and gathers are uncalibrated -- appl
 import collections
 import csv
 import json
+import re
 import sys
 
 FAMILIES = [
@@ -17,7 +18,7 @@ FAMILIES = [
     ("spconv_gemm (fwd + dgrad)", lambda n: "spconv_gemm" in n),
     ("bn2d backward (reduce, finalize, apply)", lambda n: "bn2d_bwd" in n or ("bn2d_finalize" in n and "BwdFin" in n)),
     ("bn2d forward (stats, finalize, apply)", lambda n: "bn2d_" in n),
-    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: "conv_igemm_kernel" in n and n.rstrip(">").rstrip().endswith("true")),
+    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*true>", n) is not None),
     ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n),
     ("conv2d wgrad (main kernel)", lambda n: "conv_wgrad_kernel" in n),
     ("conv weight transpose", lambda n: "conv_weight_transpose" in n),

@@ -29,6 +29,7 @@ elif [ "$part" = B ]; then
   run timeout -k 10 200 python3 tools/wgrad_layers.py > $O/sparse_layers.json 2> $O/wgrad_layers.err || exit 1
 elif [ "$part" = C ]; then
   # hardware counters: one counter per pass, kernel trace only (the pool refuses / hangs on wider combinations)
+  export BENCH_NO_WORK=1
   run timeout -k 10 170 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o fetch -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 1
   run timeout -k 10 170 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o write -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err || exit 1
   python3 tools/pmc_step.py $O/pmc_f/fetch_counter_collection.csv $O/pmc_w/write_counter_collection.csv 5 > $O/pmc_traffic.json
