@@ -11,10 +11,11 @@ its own batch, there is no data-path collective, scaling is weak.  Rank 0 prints
 
 The workload registry below names what one step contains; `config.workload` in the JSON line
 says which one ran.  `roofline` is for the dominant hand-written op of the workload (the one with
-the largest accumulated time: a sparse-conv op in `full` / `lidar_*`, lift_splat_fwd in
-`camera_only`, bev_pool_fwd in `hotpath_v1`); `roofline_ops` lists every hand-written op of the
+the largest time per step: the fused BatchNorm backward in `full` / `camera_only`, a sparse-conv op
+in `lidar_*`, bev_pool_fwd in `hotpath_v1`); `roofline_ops` lists every hand-written op of the
 hot path with its own fraction.  Times are HIP events recorded by the library on the op's own
-stream (bfhip_profile_*).  `cpu_baseline` (rank 0, N = 1) times the reference's CPU formulation
+stream (bfhip_profile_*) inside the timed region: the sparse / lift-splat / voxel ops on every step,
+the dense ops (conv2d_*, bn2d_*: ~280 more event pairs per step) on every 10th step.  `cpu_baseline` (rank 0, N = 1) times the reference's CPU formulation
 of the path on all host cores: C oracle voxelization, restated QuickCumsum bev_pool, the 21-layer
 sparse encoder as gather -> mm -> index_add_, and the config-0 forward of one frame
 (oracle/cpu_pipeline.py); it is a reported baseline, never the thing measured.
@@ -693,7 +694,7 @@ def main():
         for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
-                pmc_src = "profiles/" + cand + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate run; not measured by this run)"
+                pmc_src = "profiles/" + cand + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of the same workload, per step; correction per op in that file's hbm_bytes_note; not measured by this run)"
                 break
             except (OSError, KeyError, ValueError):
                 continue
