@@ -160,3 +160,40 @@ def test_bn2d_tiny_and_odd_sizes(dev):
         y.backward(g)
         yr.backward(g)
         assert rel(x.grad, xr.grad) < 1e-3 or float(xr.grad.abs().max()) < 1e-6, shape
+
+
+def test_bn2d_fold_finalize_opt_in_path():
+    """BFHIP_BN2D_FOLD=1 (finalize in the last-arriving block of the reduction launch; measured slower, default off) must stay
+    correct: the library reads the switch once per process, so the check runs in a child process over several shapes, twice
+    per shape (the arrival counters must come back to zero between launches), against the default path's results."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import bevfusion_amd
+from bevfusion_amd import bn2d
+dev = torch.device("cuda:0")
+out = []
+for shape in [(6, 64, 33, 47), (2, 2048, 8, 22), (24, 256, 32, 88), (3, 328, 9, 11)]:
+    for rep in range(2):
+        torch.manual_seed(1)
+        x = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        bn = bn2d.BatchNorm2dAct(shape[1]).to(dev).train()
+        y = bn(x, relu=True)
+        y.backward(torch.ones_like(y))
+        out.append(torch.cat([y.float().flatten()[:4096], x.grad.float().flatten()[:4096], bn.weight.grad, bn.running_var]).cpu())
+torch.save(out, sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for fold in ("0", "1"):
+            path = os.path.join(d, "out%s.pt" % fold)
+            env = dict(os.environ, BFHIP_BN2D_FOLD=fold)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+            res[fold] = torch.load(path, weights_only=True)
+    for a, b in zip(res["0"], res["1"]):
+        # same partial sums, same fixed-order fp64 combine up to the grouping of the tree: last-bit differences only
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
