@@ -15,6 +15,8 @@ Layer shapes follow the reference:
                       mmdet3d/models/dense_heads/centerpoint_head.py:20-121).  Target assignment, losses and
                       box decoding are "next" rows.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -28,16 +30,30 @@ from .registry import MODELS
 
 
 # ----------------------------------------------------------------------------- image backbone
+# Which convolutions of the ResNet-50 trunk take csrc/conv2d.hip (BFHIP_RESNET_CONV): "lib" = none (MIOpen / CK through
+# torch, default), "hip3x3" = the sixteen 3x3 convolutions, "hip" = the 1x1 ones as well.  (The 7x7 stem has 3 input channels
+# and always stays on the library.)  Measured on one box, ms per `full` step: lib 34.84 / 34.51, hip3x3 34.65, hip 35.28 -- the
+# 3x3 layers are a wash (the HIP kernels save the BatchNorm statistics pass and MIOpen's zero-fill / cast helpers and lose
+# 10-25 % in the forward), the 1x1 layers (K = 64 ... 512: one to eight K steps per tile, HBM-bound) run at half the library's
+# rate in the forward.  Routing them through F.linear (hipBLASLt) instead was also measured: 41.3 ms (its weight-gradient GEMMs
+# over 270 k-row operands are slow).
+_RESNET_CONV = os.environ.get("BFHIP_RESNET_CONV", "lib")
+
+
+_Conv3x3 = Conv2d if _RESNET_CONV in ("hip", "hip3x3") else nn.Conv2d
+_Conv1x1 = Conv2d if _RESNET_CONV == "hip" else nn.Conv2d
+
+
 class _Bottleneck(nn.Module):
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = _Conv1x1(inplanes, planes, 1, bias=False)
         self.bn1 = BatchNorm2dAct(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.conv2 = _Conv3x3(planes, planes, 3, stride=stride, padding=1, bias=False)
         self.bn2 = BatchNorm2dAct(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = _Conv1x1(planes, planes * 4, 1, bias=False)
         self.bn3 = BatchNorm2dAct(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -69,7 +85,7 @@ class ResNet50(nn.Module):
     def _make_layer(self, planes, blocks, stride):
         down = None
         if stride != 1 or self.inplanes != planes * 4:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+            down = nn.Sequential(_Conv1x1(self.inplanes, planes * 4, 1, stride=stride, bias=False),
                                  BatchNorm2dAct(planes * 4))
         layers = [_Bottleneck(self.inplanes, planes, stride, down)]
         self.inplanes = planes * 4
