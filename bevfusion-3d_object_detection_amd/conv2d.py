@@ -22,7 +22,8 @@ from torch import nn
 from . import _lib
 
 ENABLED = os.environ.get("BFHIP_CONV2D", "1") == "1"
-MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))  # tiny maps: the library's small-problem kernels win
+MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))
+HYBRID_HIP_DGRAD = os.environ.get("BFHIP_HYBRID_HIP_DGRAD", "0") == "1"  # Conv2dHipWgrad: data gradient on the HIP kernel too  # tiny maps: the library's small-problem kernels win
 _WS = {}
 
 
@@ -120,6 +121,49 @@ class _Conv2dFunction(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _LibConvHipWgradFunction(torch.autograd.Function):
+    """Forward and data gradient by the library convolution (MIOpen / CK through torch), weight gradient by csrc/conv2d.hip:
+    for layers where the library's forward is ahead (ResNet-50's 1x1 and 3x3 convolutions) but its weight gradient brings an
+    fp32 zero-fill and a cast launch per call (atomic split-K) and is no faster than the HIP one."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, dil):
+        x = _as_nhwc_bf16(x)
+        w = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+        with torch.autocast("cuda", enabled=False):
+            y = F.conv2d(x, w, None, stride, pad, dil)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad, dil)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil = ctx.geom
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        dy = _as_nhwc_bf16(dy)
+        OH, OW = dy.shape[2], dy.shape[3]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # (the HIP data gradient here instead was measured: + 0.4 ms per step on the ResNet-50 trunk)
+            w = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride] * 2, [pad] * 2, [dil] * 2, False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            stream = _lib.stream_of(x)
+            lib = _lib.load()
+            out_bf16 = weight.dtype == torch.bfloat16
+            dw = torch.empty((Cout, KH, KW, Cin), dtype=weight.dtype if out_bf16 else torch.float32,
+                             device=x.device).permute(0, 3, 1, 2)
+            ws = _workspace(x.device, lib.bfhip_conv2d_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, KH, KW), stream)
+            _lib.call("bfhip_conv2d_wgrad", x.data_ptr(), _nhwc_view(x), dy.data_ptr(), _nhwc_view(dy), dw.data_ptr(), N, H, W, Cin,
+                      Cout, KH, KW, stride, pad, dil, 1 if out_bf16 else 0, ws.data_ptr(), ws.numel(), stream)
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        return dx, dw, None, None, None
+
+
 def _one(v):
     if isinstance(v, (tuple, list)):
         return v[0] if all(a == v[0] for a in v) else None
@@ -159,3 +203,13 @@ class Conv2d(nn.Conv2d):
         if partial is not None:
             y._bfhip_stat_partial = partial  # picked up by the fused BatchNorm that follows (bn2d.BatchNorm2dAct)
         return y
+
+
+class Conv2dHipWgrad(Conv2d):
+    """nn.Conv2d (bias-free) whose forward and data gradient stay on the library and whose weight gradient runs on
+    csrc/conv2d.hip (see _LibConvHipWgradFunction); falls back to nn.Conv2d when the call is not one the HIP kernel serves."""
+
+    def forward(self, x):
+        if self.bias is not None or not self.training or not self.hip_eligible(x):
+            return nn.Conv2d.forward(self, x)
+        return _LibConvHipWgradFunction.apply(x, self.weight, _one(self.stride), _one(self.padding), _one(self.dilation))

@@ -23,25 +23,28 @@ from torch import nn
 
 from . import _lib
 from .bn2d import BatchNorm2dAct, BatchNormRows, bn_act
-from .conv2d import Conv2d
+from .conv2d import Conv2d, Conv2dHipWgrad
 from .linear_rows import linear_rows
 from . import attention as split_attention
 from .registry import MODELS
 
 
 # ----------------------------------------------------------------------------- image backbone
-# Which convolutions of the ResNet-50 trunk take csrc/conv2d.hip (BFHIP_RESNET_CONV): "lib" = none (MIOpen / CK through
-# torch, default), "hip3x3" = the sixteen 3x3 convolutions, "hip" = the 1x1 ones as well.  (The 7x7 stem has 3 input channels
-# and always stays on the library.)  Measured on one box, ms per `full` step: lib 34.84 / 34.51, hip3x3 34.65, hip 35.28 -- the
+# Which parts of the ResNet-50 trunk's convolutions take csrc/conv2d.hip (BFHIP_RESNET_CONV): "hipwgrad" (default) = the
+# weight gradients only, forward and data gradient stay on MIOpen / CK through torch (conv2d.Conv2dHipWgrad): 34.28 / 34.30 ms
+# per `full` step against 34.61 / 34.61 ms for "lib" on the same box -- the library's weight gradient brings an fp32 zero-fill and
+# a cast launch per call and is no faster than the HIP one; "lib" = nothing; "hip3x3" = the sixteen 3x3 convolutions entirely;
+# "hip" = the 1x1 ones as well.  (The 7x7 stem has 3 input channels and always stays on the library.)  Measured on one box, ms
+# per `full` step: lib 34.84 / 34.51, hip3x3 34.65, hip 35.28 -- the
 # 3x3 layers are a wash (the HIP kernels save the BatchNorm statistics pass and MIOpen's zero-fill / cast helpers and lose
 # 10-25 % in the forward), the 1x1 layers (K = 64 ... 512: one to eight K steps per tile, HBM-bound) run at half the library's
 # rate in the forward.  Routing them through F.linear (hipBLASLt) instead was also measured: 41.3 ms (its weight-gradient GEMMs
 # over 270 k-row operands are slow).
-_RESNET_CONV = os.environ.get("BFHIP_RESNET_CONV", "lib")
+_RESNET_CONV = os.environ.get("BFHIP_RESNET_CONV", "hipwgrad")
 
 
-_Conv3x3 = Conv2d if _RESNET_CONV in ("hip", "hip3x3") else nn.Conv2d
-_Conv1x1 = Conv2d if _RESNET_CONV == "hip" else nn.Conv2d
+_Conv3x3 = Conv2d if _RESNET_CONV in ("hip", "hip3x3") else (Conv2dHipWgrad if _RESNET_CONV == "hipwgrad" else nn.Conv2d)
+_Conv1x1 = Conv2d if _RESNET_CONV == "hip" else (Conv2dHipWgrad if _RESNET_CONV == "hipwgrad" else nn.Conv2d)
 
 
 class _Bottleneck(nn.Module):

@@ -84,6 +84,37 @@ def test_forward_backward_vs_torch_cpu(dev, g):
         assert _rel(bg.grad.cpu(), br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("g", [(3, 32, 88, 64, 256, 1, 1, 0, 1, False),     # ResNet bottleneck 1x1 expand
+                               (3, 32, 88, 128, 128, 3, 2, 1, 1, False),    # ResNet 3x3 stride 2
+                               (2, 44, 52, 256, 64, 1, 1, 0, 1, False)],    # 1x1 reduce
+                         ids=lambda g: "x".join(str(v) for v in g[:9]))
+def test_library_forward_hip_wgrad_hybrid(dev, g):
+    """Conv2dHipWgrad (the ResNet-50 trunk's convolutions): forward and data gradient by the library, weight gradient by
+    csrc/conv2d.hip; same tolerances as the all-HIP path against torch on the CPU in fp32."""
+    from bevfusion_amd.conv2d import Conv2dHipWgrad
+    N, H, W, Cin, Cout, k, s, p, d, _ = g
+    x, w, _ = _case(g, seed=sum(g[:9]))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=s, padding=p, dilation=d)
+    gy = _bf16_round(np.random.default_rng(9).standard_normal(tuple(ref.shape)).astype(np.float32))
+    ref.backward(gy)
+    conv = Conv2dHipWgrad(Cin, Cout, k, stride=s, padding=p, dilation=d, bias=False).to(dev).train()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    conv.to(memory_format=torch.channels_last)
+    xg = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(xg)
+    assert y.dtype == torch.bfloat16 and _rel(y.float().cpu(), ref.detach()) < 1e-2
+    y.backward(gy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert _rel(xg.grad.float().cpu(), xr.grad) < 1e-2 and _l2(xg.grad.float().cpu(), xr.grad) < 4e-3
+    assert conv.weight.grad.dtype == torch.float32 and _rel(conv.weight.grad.cpu(), wr.grad) < 1e-4
+    # evaluation mode / ineligible calls take nn.Conv2d as is
+    conv.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert _rel(conv(xg).float().cpu(), ref.detach()) < 1e-2
+
+
 def test_fp32_output_is_exact_on_integer_data(dev):
     """Integer-valued operands: every product and partial sum is exact in fp32, so the fp32-output forward / dgrad and the
     weight gradient must equal torch's CPU result bit for bit -- whatever the summation order.  Catches any misplaced
