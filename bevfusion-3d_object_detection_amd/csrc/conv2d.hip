@@ -54,6 +54,11 @@ struct ConvGeom {
   int Kout;        // GEMM columns (output channels of this GEMM)
   int ldw;         // weight row pitch in elements (= KH * KW * C)
   int ldy;         // output pixel pitch in elements
+  // parity-class data gradient (MODE 2): class c owns row tiles [cls[c].tile0, cls[c + 1].tile0); its rows are the pixels
+  // (h0 + i * stride, w0 + j * stride), i < Hc, j < Wc, of every image, and only the taps kh = kh0 + a * stride (a < nkh),
+  // kw = kw0 + b * stride (b < nkw) reach them (none: nkh * nkw = 0, the class's gradient is zero)
+  struct ParityClass { int h0, w0, Hc, Wc, kh0, kw0, nkh, nkw, tile0; } cls[17];
+  int ncls;
 };
 
 __device__ __forceinline__ unsigned rne_bf16(float f) {
@@ -102,10 +107,25 @@ __device__ __forceinline__ const bf16_t *piece_src(const bf16_t *x, const ConvGe
 
 // ---- epilogue of the implicit-GEMM kernel: (optional) BatchNorm statistics of the raw accumulators, then
 // accumulators -> LDS [BM][BN] -> 16-byte coalesced stores.  M rows, Kout columns, row pitch ldy.
-template <int WGM, int WGN, int MI, int NI, bool OUT_F32>
+// RowMap: GEMM row -> output pixel index (identity except for the parity-class data gradient)
+struct RowIdentity {
+  __device__ __forceinline__ long long operator()(long long m) const { return m; }
+};
+struct RowParityClass {
+  int Hc, Wc, H, W, h0, w0, stride;
+  __device__ __forceinline__ long long operator()(long long m) const {
+    const int n = (int)(m / ((long long)Hc * Wc));
+    const int rem = (int)(m - (long long)n * Hc * Wc);
+    const int i = rem / Wc, j = rem - i * Wc;
+    return ((long long)n * H + h0 + i * stride) * W + w0 + j * stride;
+  }
+};
+
+template <int WGM, int WGN, int MI, int NI, bool OUT_F32, typename RowMap = RowIdentity>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned char *smem, int tm, long long m0, int n0,
                                                long long M, int Kout, int ldy, const float *__restrict__ bias,
-                                               void *__restrict__ y, float *__restrict__ stat_partial) {
+                                               void *__restrict__ y, float *__restrict__ stat_partial,
+                                               RowMap row_map = RowMap()) {
   constexpr int NTHREADS = WGM * WGN * 64;
   constexpr int BN = WGN * NI * 32, BM = WGM * MI * 32;
   constexpr int PR = BM / 128;   // statistics partial rows of this tile (one per 128 pixels)
@@ -180,7 +200,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned c
     const long long m = m0 + row;
     const int col = n0 + c * EPC;
     if (m >= M || col >= Kout) continue;
-    unsigned char *dst = (unsigned char *)y + ((size_t)m * ldy + col) * ESZ;
+    unsigned char *dst = (unsigned char *)y + ((size_t)row_map(m) * ldy + col) * ESZ;
     const unsigned char *src = smem + row * ROWB + c * 16;
     if (col + EPC <= Kout && (((uintptr_t)dst) & 15) == 0) *(uint4 *)dst = *(const uint4 *)src;
     else
@@ -202,10 +222,14 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned c
 //   <4, 2, 2, 2, 3> : 256 x 128 tiles with 64 x 64 wave tiles and a three-stage ring -- measured, no gain (BFHIP_CONV_BIG_TILES)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WGM, int WGN, int MI, int NI, int STAGES, bool OUT_F32, bool TR>
+// MODE 0: forward gather; 1: data gradient (transposed gather over all taps, rows = all input pixels); 2: data gradient of a
+// strided convolution, one parity class of input pixels per launch: a pixel (ih, iw) is reached only by the taps with
+// kh = (ih + pad) mod stride (mod stride), so the class walks KH*KW / stride^2 of the taps instead of meeting holes at the rest
+template <int WGM, int WGN, int MI, int NI, int STAGES, bool OUT_F32, int MODE>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_igemm_kernel(
     const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt, const float *__restrict__ bias, void *__restrict__ y,
     float *__restrict__ stat_partial, ConvGeom g, int tiles_m, int tiles_n) {
+  constexpr bool TR = MODE != 0;
   constexpr int NWAVES = WGM * WGN, NTHREADS = NWAVES * 64;
   constexpr int BN = WGN * NI * 32, BM = WGM * MI * 32, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, S_BYTES = A_BYTES + B_BYTES;
@@ -217,14 +241,34 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
   unsigned *taps = (unsigned *)(smem + STAGES * S_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles_m * tiles_n);
-  const int tn = (int)(lb % tiles_n), tm = (int)(lb / tiles_n);
+  const int tn = (int)(lb % tiles_n);
+  int tm = (int)(lb / tiles_n);
+  long long M = g.M;  // GEMM rows and K pieces of this workgroup's problem (MODE 2: of its parity class)
+  int nq = g.nq;
+  ConvGeom::ParityClass pc = {};
+  if (MODE == 2) {
+    int c = 0;
+    while (c + 1 < g.ncls && tm >= g.cls[c + 1].tile0) ++c;
+    pc = g.cls[c];
+    tm -= pc.tile0;
+    M = (long long)g.N * pc.Hc * pc.Wc;
+    nq = pc.nkh * pc.nkw * (g.C >> 3);
+  }
   const long long m0 = (long long)tm * BM;
   const int n0 = tn * BN;
 
-  for (int q = tid; q < g.nq; q += NTHREADS) {
+  for (int q = tid; q < nq; q += NTHREADS) {
     int k = q * 8;
     int tap = k / g.C, ci = k - tap * g.C;
-    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    int kh, kw;
+    if (MODE == 2) {  // the class's taps only (dilation 1)
+      const int a = tap / pc.nkw;
+      kh = pc.kh0 + a * g.stride;
+      kw = pc.kw0 + (tap - a * pc.nkw) * g.stride;
+    } else {
+      kh = tap / g.KW;
+      kw = tap - kh * g.KW;
+    }
     taps[q] = ((unsigned)(kh * g.dil) << 24) | ((unsigned)(kw * g.dil) << 16) | (unsigned)ci;
   }
 
@@ -235,11 +279,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     long long m = m0 + w * (NA * 8) + i * 8 + lrow;
-    rok[i] = m < g.M;
+    rok[i] = m < M;
     long long mm = rok[i] ? m : 0;
-    int n = (int)(mm / ((long long)g.OH * g.OW));
-    int rem = (int)(mm - (long long)n * g.OH * g.OW);
-    int oh = rem / g.OW, ow = rem - oh * g.OW;
+    int n, oh, ow;
+    if (MODE == 2) {
+      const int Hc = pc.Hc, Wc = pc.Wc;
+      n = (int)(mm / ((long long)Hc * Wc));
+      const int rem = (int)(mm - (long long)n * Hc * Wc);
+      const int ci_ = rem / Wc;
+      oh = pc.h0 + ci_ * g.stride;
+      ow = pc.w0 + (rem - ci_ * Wc) * g.stride;
+    } else {
+      n = (int)(mm / ((long long)g.OH * g.OW));
+      const int rem = (int)(mm - (long long)n * g.OH * g.OW);
+      oh = rem / g.OW;
+      ow = rem - oh * g.OW;
+    }
     nb[i] = n * g.H * g.W;
     hb[i] = TR ? oh + g.pad : oh * g.stride - g.pad;
     wb[i] = TR ? ow + g.pad : ow * g.stride - g.pad;
@@ -252,7 +307,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
   }
   __syncthreads();  // tap table ready
 
-  const int nt = (g.nq + 7) >> 3;
+  const int nt = (nq + 7) >> 3;
   const bf16_t *zsrc = zero_src();
   auto stage = [&](int t, int buf) {  // exactly GL DMA instructions per wave (the counted waits rely on it)
     unsigned char *dA = smem + buf * S_BYTES + (w * (NA * 8)) * 128;
@@ -261,14 +316,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
     for (int i = 0; i < NA; ++i) {
       const int swz = ((w * (NA * 8) + i * 8 + lrow) >> 1) & 7;
       const int q = t * 8 + (lpos ^ swz);
-      const bf16_t *src = q < g.nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q], zsrc) : zsrc;
+      const bf16_t *src = q < nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q], zsrc) : zsrc;
       glds16(src, dA + i * 1024);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int swz = ((w * (NB * 8) + i * 8 + lrow) >> 1) & 7;
       const int q = t * 8 + (lpos ^ swz);
-      const bf16_t *src = (wrow[i] && q < g.nq) ? wrow[i] + (size_t)q * 8 : zsrc;
+      const bf16_t *src = zsrc;
+      if (wrow[i] && q < nq) {
+        if (MODE == 2) {  // the weight row holds all taps: this piece's tap is (dh, dw) of the table entry
+          const unsigned info = taps[q];
+          src = wrow[i] + ((size_t)((info >> 24) * g.KW + ((info >> 16) & 0xff)) * g.C + (info & 0xffff));
+        } else {
+          src = wrow[i] + (size_t)q * 8;
+        }
+      }
       glds16(src, dB + i * 1024);
     }
   };
@@ -314,7 +377,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
     buf = buf + 1 == STAGES ? 0 : buf + 1;
     nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
   }
-  igemm_epilogue<WGM, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, g.M, g.Kout, g.ldy, bias, y, stat_partial);
+  if (MODE == 2)
+    igemm_epilogue<WGM, WGN, MI, NI, OUT_F32, RowParityClass>(acc, smem, tm, m0, n0, M, g.Kout, g.ldy, bias, y, stat_partial,
+                                                              RowParityClass{pc.Hc, pc.Wc, g.OH, g.OW, pc.h0, pc.w0, g.stride});
+  else
+    igemm_epilogue<WGM, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, M, g.Kout, g.ldy, bias, y, stat_partial);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -719,7 +786,16 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
   if (tile256 && !out_f32 && g.Kout > 128 && (fits256 || tile256 == 2)) shape = 2;
   else if (shape == 1 && force_big && ceil_div(g.M, 256) * ceil_div(g.Kout, 128) >= 192) shape = 3;
   const int BM = shape >= 2 ? 256 : 128, BN = shape == 2 ? 256 : (shape == 0 ? 64 : 128), stages = shape == 3 ? 3 : 2;
-  const int tiles_m = ceil_div(g.M, BM), tiles_n = ceil_div(g.Kout, BN);
+  int tiles_m = ceil_div(g.M, BM);
+  const int tiles_n = ceil_div(g.Kout, BN);
+  if (g.transposed == 2) {  // row tiles class by class
+    tiles_m = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+      g.cls[c].tile0 = tiles_m;
+      tiles_m += ceil_div((long long)g.N * g.cls[c].Hc * g.cls[c].Wc, BM);
+    }
+    g.cls[g.ncls].tile0 = tiles_m;
+  }
   const size_t lds = igemm_lds_bytes(BM, BN, stages, g.nq);
   dim3 grid((unsigned)((long long)tiles_m * tiles_n));
 #define BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, TRV)                                                                    \
@@ -733,7 +809,7 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
     hipLaunchKernelGGL((conv_igemm_kernel<WGMV, WGNV, MIV, NIV, ST, F32, TRV>), grid, dim3(WGMV * WGNV * 64), lds, s,   \
                        (const bf16_t *)x, (const bf16_t *)wt, bias, y, stat_partial, g, tiles_m, tiles_n);             \
   } while (0)
-#define BFHIP_IG2(WGMV, WGNV, MIV, NIV, ST, F32) do { if (g.transposed) BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, true); else BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, false); } while (0)
+#define BFHIP_IG2(WGMV, WGNV, MIV, NIV, ST, F32) do { if (g.transposed == 2) BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, 2); else if (g.transposed) BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, 1); else BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, 0); } while (0)
   if (shape == 2) BFHIP_IG2(2, 4, 4, 2, 2, false);
   else if (shape == 3) { if (out_f32) BFHIP_IG2(4, 2, 2, 2, 3, true); else BFHIP_IG2(4, 2, 2, 2, 3, false); }
   else if (shape == 1) { if (out_f32) BFHIP_IG2(2, 2, 2, 2, 2, true); else BFHIP_IG2(2, 2, 2, 2, 2, false); }
@@ -753,7 +829,7 @@ BFHIP_EXPORT int bfhip_conv2d_fwd(const void *x, int ldx, const void *w, const f
   BFHIP_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
   BFHIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ldx % 8 == 0 && ldx >= Cin && ldy >= Cout,
                 "conv2d_fwd: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
-  ConvGeom g;
+  ConvGeom g = {};
   g.N = N; g.H = H; g.W = W; g.C = Cin; g.ldx = ldx;
   g.OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   g.OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
@@ -790,7 +866,7 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
   prof_begin(BFHIP_OP_CONV2D_DGRAD, s, &ps);
   hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW), dim3(256), 0, s,
                      (const bf16_t *)w, (bf16_t *)workspace, Cout, KH * KW, Cin);
-  ConvGeom g;
+  ConvGeom g = {};
   g.N = N; g.H = OH; g.W = OW; g.C = Cout; g.ldx = ldg;   // gathered tensor = dy
   g.OH = H; g.OW = W;                                    // GEMM rows = input pixels
   g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil; g.transposed = 1;
@@ -800,6 +876,27 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
   g.nq = KH * KW * Cout / 8;
   g.M = (long long)N * H * W;
   g.Kout = Cin; g.ldw = KH * KW * Cout; g.ldy = ldx;
+  static const int parity = [] { const char *e = getenv("BFHIP_CONV_DGRAD_PARITY"); return e ? atoi(e) : 1; }();
+  if (stride > 1 && stride <= 4 && dil == 1 && parity) {
+    // parity classes of the input pixels: (ih + pad) mod stride selects the kh that reach a pixel (ConvGeom::cls); one launch,
+    // row tiles class by class; g.nq stays the full tap count (it sizes the tap table), g.M the full row count (tile shape)
+    g.transposed = 2;
+    g.ncls = 0;
+    for (int ph = 0; ph < stride; ++ph)
+      for (int pw = 0; pw < stride; ++pw) {
+        ConvGeom::ParityClass &c = g.cls[g.ncls];
+        c.kh0 = ph; c.kw0 = pw;
+        c.nkh = ph < KH ? (KH - ph + stride - 1) / stride : 0;
+        c.nkw = pw < KW ? (KW - pw + stride - 1) / stride : 0;
+        if (c.nkh == 0 || c.nkw == 0) c.nkh = c.nkw = 0;
+        c.h0 = ((ph - pad) % stride + stride) % stride;
+        c.w0 = ((pw - pad) % stride + stride) % stride;
+        c.Hc = c.h0 < H ? (H - c.h0 + stride - 1) / stride : 0;
+        c.Wc = c.w0 < W ? (W - c.w0 + stride - 1) / stride : 0;
+        c.tile0 = 0;
+        if (c.Hc > 0 && c.Wc > 0) ++g.ncls;
+      }
+  }
   const int rc = launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad");
   prof_end(&ps);
   return rc;
