@@ -22,7 +22,10 @@ from torch import nn
 from . import _lib
 
 ENABLED = os.environ.get("BFHIP_CONV2D", "1") == "1"
-MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))
+MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))  # tiny maps: the library's small-problem kernels win
+# layers with fewer input channels stay on the library: the one such layer of the model (dtransform 8 -> 32, 5x5 stride 4 on the
+# 256 x 704 depth images) has an 8-column data gradient over 4.3 M rows -- 0.30 ms on 64-column tiles; 33.43 vs 33.70 ms per step
+MIN_CIN = int(os.environ.get("BFHIP_CONV2D_MIN_CIN", "16"))
 HYBRID_HIP_DGRAD = os.environ.get("BFHIP_HYBRID_HIP_DGRAD", "0") == "1"  # Conv2dHipWgrad: data gradient on the HIP kernel too  # tiny maps: the library's small-problem kernels win
 _WS = {}
 
@@ -190,7 +193,7 @@ class Conv2d(nn.Conv2d):
         if s is None or p is None or d is None:
             return False
         N, Cin, H, W = x.shape
-        if N * H * W < MIN_PIXELS:
+        if N * H * W < MIN_PIXELS or Cin < MIN_CIN:
             return False
         return bool(_lib.load().bfhip_conv2d_supported(N, H, W, Cin, self.out_channels, self.kernel_size[0], self.kernel_size[1],
                                                        s, p, d))
