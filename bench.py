@@ -363,8 +363,8 @@ class _ModelWorkload:
         """Algorithmic flops / bytes of the hand-written dense ops (csrc/conv2d.hip, csrc/bn2d.hip) of one step, from one
         instrumented forward: every call's shape is recorded at the Python entry of the op."""
         from bevfusion_amd import bn2d as b2, conv2d as c2
-        convs, bns = [], []
-        orig_c, orig_b = c2._Conv2dFunction.forward, b2._apply
+        convs, bns, hybrid = [], [], []
+        orig_c, orig_b, orig_h = c2._Conv2dFunction.forward, b2._apply, c2._LibConvHipWgradFunction.forward
 
         def spy_c(ctx, x, weight, bias, stride, pad, dil, emit_stats):
             N, Cin, H, W = x.shape
@@ -380,26 +380,37 @@ class _ModelWorkload:
                 bns.append((x.numel() * x.element_size(), residual is not None, has_partial))
             return orig_b(x, residual, *a, **k)
 
+        def spy_h(ctx, x, weight, stride, pad, dil):  # library forward / data gradient, HIP weight gradient (ResNet-50 trunk)
+            N, Cin, H, W = x.shape
+            Cout, _, KH, KW = weight.shape
+            OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+            OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+            hybrid.append((N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin))
+            return orig_h(ctx, x, weight, stride, pad, dil)
+
         c2._Conv2dFunction.forward, b2._apply = staticmethod(spy_c), spy_b
+        c2._LibConvHipWgradFunction.forward = staticmethod(spy_h)
         try:
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
                 self.step_model(self.inputs, None, self.gts)
         finally:
             c2._Conv2dFunction.forward, b2._apply = staticmethod(orig_c), orig_b
+            c2._LibConvHipWgradFunction.forward = staticmethod(orig_h)
         work = {}
         peak, note = MFMA_PEAK_BF16
 
-        def conv_entry(sel, scope):
-            rows = [c for c in convs if sel(c)]
+        def conv_entry(sel, scope, extra=()):
+            rows = [c for c in convs if sel(c)] + list(extra)
             fl = sum(2.0 * m * k * co for m, k, co, _, _ in rows)
             by = sum((xin + m * co + k * co) * 2 for m, k, co, _, xin in rows)
             bound = "mfma" if fl / max(by, 1) * HBM_PEAK_GBS * 1e9 > peak * 1e12 else "hbm"
             return dict(bound=bound, flops=fl, bytes=by, unit_peak=peak, peak_note=note, scope="%d launches per step: %s" % (len(rows), scope))
 
-        if convs:
+        if convs or hybrid:
             work["conv2d_fwd"] = conv_entry(lambda c: True, "implicit-GEMM forward of the BEV / view-transform / LSS-FPN convolutions (csrc/conv2d.hip)")
             work["conv2d_dgrad"] = conv_entry(lambda c: c[3], "weight transpose + implicit GEMM in transposed-gather mode")
-            work["conv2d_wgrad"] = conv_entry(lambda c: True, "pixel-major LDS tiles, transposing LDS reads, split pixel range + fixed-order slab sum")
+            work["conv2d_wgrad"] = conv_entry(lambda c: True, "pixel-major LDS tiles, transposing LDS reads, split pixel range + fixed-order slab sum "
+                                              "(incl. the %d ResNet-50 layers whose forward / data gradient stay on the library)" % len(hybrid), extra=hybrid)
         if bns:
             # forward: statistics pass (unless the producing conv accumulated them) + apply (read, write) [+ residual read];
             # backward: reduce (dy, x) + apply (dy, x -> dx) [+ y read and d_residual write for residual layers]
