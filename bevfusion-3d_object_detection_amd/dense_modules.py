@@ -39,12 +39,12 @@ from .registry import MODELS
 # 3x3 layers are a wash (the HIP kernels save the BatchNorm statistics pass and MIOpen's zero-fill / cast helpers and lose
 # 10-25 % in the forward), the 1x1 layers (K = 64 ... 512: one to eight K steps per tile, HBM-bound) run at half the library's
 # rate in the forward.  Routing them through F.linear (hipBLASLt) instead was also measured: 41.3 ms (its weight-gradient GEMMs
-# over 270 k-row operands are slow).
+# over 270 k-row operands are slow).  "hip3x3+hipwgrad" (HIP 3x3 entirely, hybrid 1x1): 34.0-34.3 vs 33.7-33.8 ms for "hipwgrad".
 _RESNET_CONV = os.environ.get("BFHIP_RESNET_CONV", "hipwgrad")
 
 
-_Conv3x3 = Conv2d if _RESNET_CONV in ("hip", "hip3x3") else (Conv2dHipWgrad if _RESNET_CONV == "hipwgrad" else nn.Conv2d)
-_Conv1x1 = Conv2d if _RESNET_CONV == "hip" else (Conv2dHipWgrad if _RESNET_CONV == "hipwgrad" else nn.Conv2d)
+_Conv3x3 = Conv2d if _RESNET_CONV in ("hip", "hip3x3", "hip3x3+hipwgrad") else (Conv2dHipWgrad if _RESNET_CONV == "hipwgrad" else nn.Conv2d)
+_Conv1x1 = Conv2d if _RESNET_CONV == "hip" else (Conv2dHipWgrad if _RESNET_CONV in ("hipwgrad", "hip3x3+hipwgrad") else nn.Conv2d)
 
 
 class _Bottleneck(nn.Module):
