@@ -231,12 +231,21 @@ __global__ __launch_bounds__(256) void plan_group_key_kernel(const unsigned *__r
 // ------------------------------------------------------------------------------ fused forward
 constexpr int kU = 8;
 
+__device__ __forceinline__ unsigned rne_bf16_bits(float f) {  // fp32 -> bf16, round to nearest even (NaN kept quiet)
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
 // cq lanes per interval, each lane owns 4 channels.  out[cell][c] = sum_i depth[pix_i, d_i] * feat[pix_i, c]
+// OUT16: the fp32 sum is rounded once and stored as bf16 (what the consumer's cast would do: the view transform's bf16
+// downsample convolution then takes the BEV map as it is)
+template <bool OUT16>
 __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
     const float *__restrict__ depth, int depth_pitch, const float *__restrict__ feat, int feat_pitch,
     const unsigned *__restrict__ pd, const int *__restrict__ starts, const int *__restrict__ lengths,
     const int *__restrict__ cell_of_interval, const int *__restrict__ counts, const int *__restrict__ order, int mmax,
-    int cq, int groups, float4 *__restrict__ out) {
+    int cq, int groups, void *__restrict__ out_) {
   const int m = min(mmax, counts[1]);
   const int lane = threadIdx.x & (kWave - 1);
   // rank order (order == NULL): round-robin block->XCD placement on purpose -- the long intervals (cells next to the ego
@@ -283,14 +292,24 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(
       }
     }
   }
-  out[(size_t)cell_of_interval[k] * cq + q] = acc;
+  const size_t o = (size_t)cell_of_interval[k] * cq + q;
+  if (OUT16) {
+    uint2 v;
+    v.x = rne_bf16_bits(acc.x) | (rne_bf16_bits(acc.y) << 16);
+    v.y = rne_bf16_bits(acc.z) | (rne_bf16_bits(acc.w) << 16);
+    ((uint2 *)out_)[o] = v;
+  } else {
+    ((float4 *)out_)[o] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------ fused backward
 // cq lanes per PIXEL.  For d in [0, D): g = out_grad[cell(p,d)] (0 if not kept)
 //   d_depth[p,d] = sum_c g[c]*feat[p,c] ;  d_feat[p,:] += depth[p,d]*g
+// G16: out_grad arrives as bf16 (the gradient of a bf16 BEV map): widened on load, same arithmetic
+template <bool G16>
 __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
-    const float4 *__restrict__ out_grad, const float *__restrict__ depth, int depth_pitch,
+    const void *__restrict__ out_grad_, const float *__restrict__ depth, int depth_pitch,
     const float *__restrict__ feat, int feat_pitch, const int *__restrict__ cell_of_point, int P_,
     int D, int HW, int cq, int groups, float *__restrict__ d_depth, int d_depth_pitch,
     float *__restrict__ d_feat, int d_feat_pitch) {
@@ -320,7 +339,17 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
     float4 gv[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u)
-      gv[u] = cell[u] >= 0 ? out_grad[(size_t)cell[u] * cq + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      if (cell[u] < 0) {
+        gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (G16) {
+        const uint2 v = ((const uint2 *)out_grad_)[(size_t)cell[u] * cq + q];
+        gv[u] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                            __uint_as_float(v.y & 0xffff0000u));
+      } else {
+        gv[u] = ((const float4 *)out_grad_)[(size_t)cell[u] * cq + q];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       // per-lane partial dot over its 4 channels (ascending), then a fixed-shape tree over the cq lanes
@@ -455,8 +484,8 @@ BFHIP_EXPORT int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const
                                       int feat_pitch, const uint32_t *sorted_pd,
                                       const int32_t *starts, const int32_t *lengths,
                                       const int32_t *cell_of_interval, const int32_t *interval_order,
-                                      const int32_t *counts_dev, int mmax, int C, long long out_cells, float *out,
-                                      void *stream_) {
+                                      const int32_t *counts_dev, int mmax, int C, long long out_cells, void *out,
+                                      int out_bf16, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BFHIP_REQUIRE(C > 0 && C % 4 == 0 && C / 4 <= kWave, "lift_splat_fwd: C must be a multiple of 4 and <= 256 (C=%d)", C);
   BFHIP_REQUIRE(feat_pitch % 4 == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)out % 16) == 0,
@@ -464,20 +493,25 @@ BFHIP_EXPORT int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const
   BFHIP_REQUIRE(depth && feat && sorted_pd && starts && lengths && cell_of_interval && counts_dev && out,
                 "lift_splat_fwd: null pointer");
   BFHIP_REQUIRE(mmax > 0 && out_cells > 0, "lift_splat_fwd: bad mmax/out_cells");
-  if (hipMemsetAsync(out, 0, (size_t)out_cells * C * sizeof(float), stream) != hipSuccess)
+  if (hipMemsetAsync(out, 0, (size_t)out_cells * C * (out_bf16 ? 2 : 4), stream) != hipSuccess)
     return check_launch("lift_splat_fwd memset");
   int cq = C / 4, groups = kWave / cq;
   long long waves = ((long long)mmax + groups - 1) / groups;
   ProfScope ps;
   prof_begin(BFHIP_OP_LIFT_SPLAT_FWD, stream, &ps);
-  hipLaunchKernelGGL(lift_splat_fwd_kernel, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
-                     depth_pitch, feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
-                     interval_order, mmax, cq, groups, (float4 *)out);
+  if (out_bf16)
+    hipLaunchKernelGGL(lift_splat_fwd_kernel<true>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
+                       depth_pitch, feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
+                       interval_order, mmax, cq, groups, out);
+  else
+    hipLaunchKernelGGL(lift_splat_fwd_kernel<false>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
+                       depth_pitch, feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
+                       interval_order, mmax, cq, groups, out);
   prof_end(&ps);
   return check_launch("lift_splat_fwd");
 }
 
-BFHIP_EXPORT int bfhip_lift_splat_bwd(const float *out_grad, const float *depth, int depth_pitch,
+BFHIP_EXPORT int bfhip_lift_splat_bwd(const void *out_grad, int grad_bf16, const float *depth, int depth_pitch,
                                       const float *feat, int feat_pitch,
                                       const int32_t *cell_of_point, int num_cams, int D, int HW,
                                       int C, float *d_depth, int d_depth_pitch, float *d_feat,
@@ -486,7 +520,7 @@ BFHIP_EXPORT int bfhip_lift_splat_bwd(const float *out_grad, const float *depth,
   BFHIP_REQUIRE(C > 0 && C % 4 == 0 && C / 4 <= kWave, "lift_splat_bwd: C must be a multiple of 4 and <= 256 (C=%d)", C);
   BFHIP_REQUIRE(num_cams > 0 && D > 0 && HW > 0, "lift_splat_bwd: bad sizes");
   BFHIP_REQUIRE(feat_pitch % 4 == 0 && d_feat_pitch % 4 == 0 && ((uintptr_t)feat % 16) == 0 &&
-                    ((uintptr_t)d_feat % 16) == 0 && ((uintptr_t)out_grad % 16) == 0,
+                    ((uintptr_t)d_feat % 16) == 0 && ((uintptr_t)out_grad % (grad_bf16 ? 8 : 16)) == 0,
                 "lift_splat_bwd: feat/d_feat/out_grad must be 16-byte aligned, pitches multiples of 4 floats");
   BFHIP_REQUIRE(out_grad && depth && feat && cell_of_point && d_depth && d_feat, "lift_splat_bwd: null pointer");
   long long npix = (long long)num_cams * HW;
@@ -494,9 +528,14 @@ BFHIP_EXPORT int bfhip_lift_splat_bwd(const float *out_grad, const float *depth,
   long long waves = (npix + groups - 1) / groups;
   ProfScope ps;
   prof_begin(BFHIP_OP_LIFT_SPLAT_BWD, stream, &ps);
-  hipLaunchKernelGGL(lift_splat_bwd_kernel, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream,
-                     (const float4 *)out_grad, depth, depth_pitch, feat, feat_pitch, cell_of_point, (int)npix, D,
-                     HW, cq, groups, d_depth, d_depth_pitch, d_feat, d_feat_pitch);
+  if (grad_bf16)
+    hipLaunchKernelGGL(lift_splat_bwd_kernel<true>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, out_grad, depth,
+                       depth_pitch, feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth, d_depth_pitch, d_feat,
+                       d_feat_pitch);
+  else
+    hipLaunchKernelGGL(lift_splat_bwd_kernel<false>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, out_grad, depth,
+                       depth_pitch, feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth, d_depth_pitch, d_feat,
+                       d_feat_pitch);
   prof_end(&ps);
   return check_launch("lift_splat_bwd");
 }

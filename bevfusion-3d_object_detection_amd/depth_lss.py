@@ -32,6 +32,7 @@ from .registry import MODELS
 # hit the per-XCD L2) but not its time (0.350 vs 0.374 ms alone, 0.379 vs 0.386 ms inside the step): the kernel is bound by
 # the per-CU rate of 320-byte row gathers through the vector L1, and the extra key sort costs 0.12 ms per plan.  Off by
 # default for that reason; on, it frees ~1 GB of Infinity-Cache / HBM traffic per step for whatever runs beside it.
+BF16_BEV_OUT = os.environ.get("BFHIP_LIFT_SPLAT_BF16_OUT", "1") == "1"  # A/B switch for lift_splat_bev's bf16 hand-over
 CAMERA_MAJOR = os.environ.get("BFHIP_LIFT_SPLAT_ORDER", "0") == "1"
 
 
@@ -103,18 +104,21 @@ class _LiftSplat(torch.autograd.Function):
     """out[b,z,x,y,:] = sum over the cell's frustum points of depth[p,d] * feat[p,:]."""
 
     @staticmethod
-    def forward(ctx, depth, feat, plan):
-        # depth [P, D] pixel-major, feat [P, C] pixel-major (any pitch, last dim contiguous)
+    def forward(ctx, depth, feat, plan, out_dtype=torch.float32):
+        # depth [P, D] pixel-major, feat [P, C] pixel-major (any pitch, last dim contiguous); out_dtype bf16: the fp32 sums are
+        # rounded once on store (what a consumer's cast would do) and the backward takes the bf16 gradient as it is
         assert depth.dim() == 2 and feat.dim() == 2 and depth.stride(1) == 1 and feat.stride(1) == 1
         assert depth.dtype == torch.float32 and feat.dtype == torch.float32
         P, C = feat.shape
         assert P == plan.B * plan.N * plan.HW and depth.shape == (P, plan.D)
-        out = torch.empty((plan.B, plan.nx[2], plan.nx[0], plan.nx[1], C), dtype=torch.float32, device=feat.device)
+        assert out_dtype in (torch.float32, torch.bfloat16)
+        out = torch.empty((plan.B, plan.nx[2], plan.nx[0], plan.nx[1], C), dtype=out_dtype, device=feat.device)
         with torch.cuda.device(feat.device):
             rc = _lib.load().bfhip_lift_splat_fwd(
                 _lib.ptr(depth), depth.stride(0), _lib.ptr(feat), feat.stride(0), _lib.ptr(plan.sorted_pd),
                 _lib.ptr(plan.starts), _lib.ptr(plan.lengths), _lib.ptr(plan.cell_of_interval), _lib.ptr(plan.interval_order),
-                _lib.ptr(plan.counts), plan.mmax, C, plan.out_cells, _lib.ptr(out), _lib.stream_of(feat))
+                _lib.ptr(plan.counts), plan.mmax, C, plan.out_cells, _lib.ptr(out), 1 if out_dtype == torch.bfloat16 else 0,
+                _lib.stream_of(feat))
         _lib.check(rc, "lift_splat_fwd")
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan
@@ -125,21 +129,24 @@ class _LiftSplat(torch.autograd.Function):
         depth, feat = ctx.saved_tensors
         plan = ctx.plan
         out_grad = out_grad.contiguous()
+        if out_grad.dtype not in (torch.float32, torch.bfloat16):
+            out_grad = out_grad.float()
         P, C = feat.shape
         d_depth = torch.empty((P, plan.D), dtype=torch.float32, device=feat.device)
         d_feat = torch.empty((P, C), dtype=torch.float32, device=feat.device)
         with torch.cuda.device(feat.device):
             rc = _lib.load().bfhip_lift_splat_bwd(
-                _lib.ptr(out_grad), _lib.ptr(depth), depth.stride(0), _lib.ptr(feat), feat.stride(0),
+                _lib.ptr(out_grad), 1 if out_grad.dtype == torch.bfloat16 else 0, _lib.ptr(depth), depth.stride(0), _lib.ptr(feat),
+                feat.stride(0),
                 _lib.ptr(plan.cell_of_point), plan.B * plan.N, plan.D, plan.HW, C, _lib.ptr(d_depth), plan.D,
                 _lib.ptr(d_feat), C, _lib.stream_of(feat))
         _lib.check(rc, "lift_splat_bwd")
-        return d_depth, d_feat, None
+        return d_depth, d_feat, None, None
 
 
-def lift_splat(depth, feat, plan):
-    """depth f32[P,D], feat f32[P,C] (pixel-major) -> BEV f32[B, nz, nx, ny, C]."""
-    return _LiftSplat.apply(depth, feat, plan)
+def lift_splat(depth, feat, plan, out_dtype=torch.float32):
+    """depth f32[P,D], feat f32[P,C] (pixel-major) -> BEV f32 (or bf16) [B, nz, nx, ny, C]."""
+    return _LiftSplat.apply(depth, feat, plan, out_dtype)
 
 
 class BaseViewTransform(nn.Module):
@@ -251,10 +258,16 @@ class BaseViewTransform(nn.Module):
             depth_pm = depth_pm.contiguous()
         if feat_pm.stride(1) != 1 or feat_pm.stride(0) % 4 or feat_pm.data_ptr() % 16:
             feat_pm = feat_pm.contiguous()
-        out = lift_splat(depth_pm.float(), feat_pm.float(), plan)  # [B, nz, nx, ny, C]
+        # with bf16 conv stacks behind it (conv_dtype) the BEV map leaves the kernel in bf16: the downsample convolution's cast
+        # and its backward (two 40 MB copies per step) disappear, the values are the ones that cast would have produced
+        # (bit-identical model results; step time unchanged within noise: 33.79 vs 33.72 ms over three runs each)
+        out_dtype = torch.bfloat16 if (BF16_BEV_OUT and getattr(self, "conv_dtype", None) == torch.bfloat16) else torch.float32
+        out = lift_splat(depth_pm.float(), feat_pm.float(), plan, out_dtype)  # [B, nz, nx, ny, C]
         if out.shape[1] == 1:
             # nz == 1 (every BEVFusion config): [B, nx, ny, C] IS the channels-last memory of [B, C, nx, ny] -> no copy
-            return out[:, 0].permute(0, 3, 1, 2)
+            # (a reshape, not out[:, 0]: the backward of a select is a zero-fill + copy)
+            B_, _, X_, Y_, C_ = out.shape
+            return out.view(B_, X_, Y_, C_).permute(0, 3, 1, 2)
         out = out.permute(0, 4, 1, 2, 3)  # [B, C, nz, nx, ny]
         return torch.cat(out.unbind(dim=2), 1).contiguous()
 

@@ -178,14 +178,17 @@ int bfhip_bev_plan(const float *frustum, const float *post_trans, const float *p
  *   x[kept][indices] :190-194 and the bev_pool op, without materialising x[N', C])
  *   depth f32[P, depth_pitch] (softmax over D bins, pixel-major), feat f32[P, feat_pitch]
  *   (C channels, pixel-major), P = B*N*HW pixels; plan arrays from bfhip_bev_plan.
- *   out f32[out_cells, C] with out_cells = B*nx2*nx0*nx1, zero-filled by the call.
+ *   out f32[out_cells, C] (out_bf16 = 1: bf16[out_cells, C], the fp32 sums rounded once on store) with
+ *   out_cells = B*nx2*nx0*nx1, zero-filled by the call.
  * bwd: d_depth[p,d] = <out_grad[cell(p,d)], feat[p]>, d_feat[p] = sum_d depth[p,d]*out_grad[cell(p,d)]
  * --------------------------------------------------------------------------------------- */
 int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const float *feat, int feat_pitch,
                          const uint32_t *sorted_pd, const int32_t *starts, const int32_t *lengths,
                          const int32_t *cell_of_interval, const int32_t *interval_order /* may be NULL: rank order */,
-                         const int32_t *counts_dev, int mmax, int C, long long out_cells, float *out, void *stream);
-int bfhip_lift_splat_bwd(const float *out_grad, const float *depth, int depth_pitch,
+                         const int32_t *counts_dev, int mmax, int C, long long out_cells, void *out, int out_bf16,
+                         void *stream);
+int bfhip_lift_splat_bwd(const void *out_grad, int grad_bf16 /* out_grad is bf16[out_cells, C] */, const float *depth,
+                         int depth_pitch,
                          const float *feat, int feat_pitch, const int32_t *cell_of_point,
                          int num_cams, int D, int HW, int C, float *d_depth, int d_depth_pitch,
                          float *d_feat, int d_feat_pitch, void *stream);

@@ -140,6 +140,30 @@ def test_lift_splat_fwd_bwd_vs_oracle(dev, train_aug):
     assert rel_err(feat.grad.cpu().numpy(), df_pm) < 1e-5
 
 
+def test_lift_splat_bf16_output_is_the_rounded_fp32_result(dev):
+    """out_dtype = bf16: the forward stores round-to-nearest-even(fp32 sum) -- bit for bit what `.to(torch.bfloat16)` of the fp32
+    output gives -- and the backward with a bf16 out_grad equals the fp32 kernel fed the widened gradient, bit for bit."""
+    cfg = dict(TINY, out_channels=80)
+    vt = LSSTransform(**cfg).to(dev)
+    B = 2
+    rig = synthetic.camera_rig(batch=B, seed=5, train_aug=True)
+    rig["img_aug_matrix"][..., 0, 0] = rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3], rig["img_aug_matrix"][..., 1, 3] = -8.0, -44.0
+    plan = vt.make_plan(**_calib(vt, rig, dev))
+    fH, fW = cfg["feature_size"]
+    BN, D, C = B * 6, vt.D, 80
+    depth, feat = _random_depth_feat(dev, BN * fH * fW, D, C, seed=2)
+    d32, f32 = depth.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    d16, f16 = depth.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    o32 = lift_splat(d32, f32, plan)
+    o16 = lift_splat(d16, f16, plan, torch.bfloat16)
+    assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.to(torch.bfloat16))
+    og = torch.randn(o32.shape, generator=torch.Generator().manual_seed(3)).to(dev).to(torch.bfloat16)
+    o32.backward(og.float())
+    o16.backward(og)
+    assert torch.equal(d16.grad, d32.grad) and torch.equal(f16.grad, f32.grad)
+
+
 def test_module_fused_equals_op_boundary_path(dev, golden_lss):
     """BaseViewTransform.bev_pool(x, geom) (the reference's materialised path through the bev_pool op)
     reproduces the reference's python-glue golden, and the fused lift-splat equals it."""
