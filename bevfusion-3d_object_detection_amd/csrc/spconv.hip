@@ -672,8 +672,6 @@ __global__ __launch_bounds__(256) void spconv_gemm_bf16_kernel(const void *__res
     for (int r = 0; r < R; ++r)
       dst[r] = (kk < KV && my_row[r] >= 0 && ((wmask >> kk) & 1u)) ? pairs[(size_t)kk * ld + my_row[r]] : -1;
   };
-  const bool lane_k_ok_base = true;
-  (void)lane_k_ok_base;
   auto gather = [&](const int *ix, int c, f32x4 *lo, f32x4 *hi) {
     const int ch = c * 32 + lq * 8;
 #pragma unroll
