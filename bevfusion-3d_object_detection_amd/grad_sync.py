@@ -112,7 +112,15 @@ class FlatGradAllReduce:
         else:
             shard = flat.numel() // W
             recv = self._buf("recv", flat)
-            dist.all_to_all_single(recv, flat, group=self.group)           # recv[r] = rank r's copy of MY shard
+            try:
+                dist.all_to_all_single(recv, flat, group=self.group)       # recv[r] = rank r's copy of MY shard
+            except RuntimeError as err:
+                # a backend without all-to-all for this tensor type (every rank fails alike, before any data moved): the
+                # widened all-reduce gives the same fp32 accumulation at twice the wire bytes
+                import warnings
+                warnings.warn("gradient exchange: all_to_all_single unavailable (%s); using the fp32 all-reduce" % err)
+                self.exchange = "allreduce_fp32"
+                return self._mean_over_ranks(flat)
             mine = self._buf("mine", flat, numel=shard)
             acc = self._buf("acc", flat, numel=shard, dtype=torch.float32)
             torch.sum(recv.view(W, shard), dim=0, dtype=torch.float32, out=acc)
