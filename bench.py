@@ -750,7 +750,9 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if getattr(wl, "amp", False) else "f32", "data": "synthetic",
             "config": {"workload": wl.name, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                        "points_per_frame": args.points, "frustum_rows_kept": wl.nk, "bev_intervals": wl.m,
-                       "parallelism": ("dp%d (%s, RCCL gradient all-reduce)" % (world, "DDP buckets" if GRAD_SYNC == "ddp" else "one flat all-reduce per dtype after the backward")) if world > 1 and hasattr(wl, "step_model")
+                       "parallelism": ("dp%d (%s)" % (world, "torch DDP buckets, RCCL all-reduce" if GRAD_SYNC == "ddp" else
+                                                      "one flat gradient exchange per dtype after the backward over RCCL: %s"
+                                                      % getattr(getattr(wl, "grad_sync", None), "exchange", "all-reduce"))) if world > 1 and hasattr(wl, "step_model")
                        else "independent frames per rank"},
             "roofline": roof, "roofline_ops": roofline_ops, "ops": ops,
         }
