@@ -785,6 +785,15 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
   const bool fits256 = t256 >= tile256_min && (long long)ceil_div(g.Kout, 256) * 256 * 8 <= (long long)g.Kout * 9;
   if (tile256 && !out_f32 && g.Kout > 128 && (fits256 || tile256 == 2)) shape = 2;
   else if (shape == 1 && force_big && ceil_div(g.M, 256) * ceil_div(g.Kout, 128) >= 192) shape = 3;
+  static const int quant = [] { const char *e = getenv("BFHIP_CONV_QUANT"); return e ? atoi(e) : 1; }();
+  if (quant && shape == 1) {
+    // 128 x 128 tiles run two workgroups per CU: a tile count just above a whole number of rounds leaves the last round almost
+    // empty; 128 x 64 tiles (three per CU) quantise finer (depthnet / LSS-FPN 3x3 on the 24 x 32 x 88 maps, 1 056 tiles = 2.06
+    // rounds: forward 0.167 -> 0.161 ms, backward 0.344 -> 0.318 ms)
+    const long long t = (long long)ceil_div(g.M, 128) * ceil_div(g.Kout, 128);
+    const double rounds = (double)t / 512.0;
+    if (rounds > 1.0 && rounds < 4.0 && rounds - (long long)rounds < 0.15) shape = 0;
+  }
   const int BM = shape >= 2 ? 256 : 128, BN = shape == 2 ? 256 : (shape == 0 ? 64 : 128), stages = shape == 3 ? 3 : 2;
   int tiles_m = ceil_div(g.M, BM);
   const int tiles_n = ceil_div(g.Kout, BN);
