@@ -32,6 +32,7 @@ GEOMS = [(2, 45, 52, 336, 256, 3, 1, 1, 1, False),   # ConvFuser (BF/bevfusion_h
          (2, 33, 47, 64, 128, 1, 2, 0, 1, False),    # 1x1 stride 2: three of the four parity classes of the data gradient have no tap
          (2, 30, 31, 32, 32, 3, 4, 1, 1, False),     # 3x3 stride 4: 7 of 16 parity classes empty, odd extents
          (1, 17, 19, 16, 16, 5, 4, 2, 1, True),      # 5x5 stride 4 on odd extents: classes with 1, 2 and 4 taps
+         (2, 132, 128, 16, 256, 3, 1, 1, 1, False),  # 528 tiles of 128 x 128 = 1.03 residency rounds: forward switches to 128 x 64 tiles
          (2, 223, 225, 16, 256, 3, 1, 1, 1, True),   # >= 384 row tiles x 256 columns: forward takes the 256 x 256 tile kernel
          (2, 223, 225, 256, 16, 3, 1, 1, 1, False)]  # ... and here the data gradient does (its GEMM columns are Cin = 256)
 
