@@ -691,6 +691,8 @@ def main():
         dt = float(tt.item())
     frames = args.batch * world * args.steps
     value = frames / dt
+    # the collective library that actually carried the gradients ("nccl" is RCCL on ROCm), not an assumption
+    backend_name = {"nccl": "RCCL"}.get(dist.get_backend(), dist.get_backend()) if dist is not None else "none"
 
     if rank == 0:
         ops = {op: {"ms_per_step": round(ms / (max(dense_steps, 1) if op in DENSE_OPS else prof_steps), 4),
@@ -750,9 +752,9 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if getattr(wl, "amp", False) else "f32", "data": "synthetic",
             "config": {"workload": wl.name, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                        "points_per_frame": args.points, "frustum_rows_kept": wl.nk, "bev_intervals": wl.m,
-                       "parallelism": ("dp%d (%s)" % (world, "torch DDP buckets, RCCL all-reduce" if GRAD_SYNC == "ddp" else
-                                                      "one flat gradient exchange per dtype after the backward over RCCL: %s"
-                                                      % getattr(getattr(wl, "grad_sync", None), "exchange", "all-reduce"))) if world > 1 and hasattr(wl, "step_model")
+                       "parallelism": ("dp%d (%s)" % (world, ("torch DDP buckets, %s all-reduce" % backend_name) if GRAD_SYNC == "ddp" else
+                                                      "flat all-reduce: one gradient exchange per dtype after the backward over %s, form %s"
+                                                      % (backend_name, getattr(getattr(wl, "grad_sync", None), "exchange", "all-reduce")))) if world > 1 and hasattr(wl, "step_model")
                        else "independent frames per rank"},
             "roofline": roof, "roofline_ops": roofline_ops, "ops": ops,
         }
