@@ -252,7 +252,7 @@ class _ModelWorkload:
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
             # BEVFusion.loss: extract_feat + TransFusion head + Hungarian targets + focal / L1 / gaussian-focal losses
             losses = self.step_model(self.inputs, None, gts)
-            loss = self.parse_losses(losses)
+            loss, self.log_vars = self.parse_losses(losses)  # (loss, log_vars) as BF/bevfusion.py:88-121
         loss.backward()
         return loss
 
@@ -260,7 +260,8 @@ class _ModelWorkload:
         if self.grad_sync is not None:
             self.grad_sync.reduce()
         if not self.master_weights:
-            torch.nn.utils.clip_grad_norm_(self._params, 35.0, foreach=True)
+            from bevfusion_amd.amp import skip_nonfinite_step
+            skip_nonfinite_step(self.opt, torch.nn.utils.clip_grad_norm_(self._params, 35.0, foreach=True))
         self.opt.step()
 
     def _eager_step(self):

@@ -46,6 +46,8 @@ SIGNATURES = {
     "bfhip_spconv_workspace_bytes": (_c_sz, [_c_int] * 3),
     "bfhip_rulebook_sort_rows_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "bfhip_rulebook_sort_rows": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "bfhip_rulebook_validate_workspace_bytes": (_c_sz, [_c_int]),
+    "bfhip_rulebook_validate": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_spconv_gemm": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_spconv_gemm_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_sz, _c_vp]),
     "bfhip_spconv_wgrad_workspace_bytes": (_c_sz, [_c_int] * 4),

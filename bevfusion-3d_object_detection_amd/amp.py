@@ -26,6 +26,15 @@ def low_precision_parameters(model, exclude=("pts_middle_encoder", "heatmap_head
     return out
 
 
+def skip_nonfinite_step(opt, total_norm):
+    """A step whose gradient norm is NaN / inf leaves parameters, moments and step counters untouched -- decided on the
+    device (the fused AdamW kernels' `found_inf` input, what GradScaler uses), no host read.  This is how a poisoned loss
+    (an invalid Hungarian cost matrix; a frame that overflowed a static row capacity, BEVFusion.loss) costs one skipped
+    step instead of NaN weights.  The reference's OptimWrapper has no such guard: with it a NaN loss ends the run."""
+    opt.found_inf = (~torch.isfinite(total_norm)).to(torch.float32).reshape(())
+    opt.grad_scale = None
+
+
 class MasterWeightAdamW:
     """AdamW (fused) over fp32 master copies of `low` (converted to bf16 in place) plus the remaining fp32 parameters."""
 
@@ -57,9 +66,15 @@ class MasterWeightAdamW:
             torch._foreach_copy_([a for a, _ in have], [b for _, b in have])  # bf16 -> fp32, one multi-tensor kernel
         if len(have) != len(self.low):
             # a parameter unused in this step: zero gradient, as the flat all-reduce path produces at world size > 1
-            # (grad_sync.FlatGradAllReduce zero-fills), so the update does not depend on the world size
+            # (grad_sync.FlatGradAllReduce zero-fills), so the update does not depend on the world size.  Deviation from
+            # torch.optim (and the reference's optimizer), which SKIP a parameter without a gradient: here it still gets its
+            # weight decay and moment decay -- for every parameter kind alike (bf16-with-master and fp32)
             torch._foreach_zero_([m.grad for m, p in zip(self.master, self.low) if p.grad is None])
+        for p in self.other:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
         if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.master + self.other, self.max_grad_norm, foreach=True)
+            norm = torch.nn.utils.clip_grad_norm_(self.master + self.other, self.max_grad_norm, foreach=True)
+            skip_nonfinite_step(self.opt, norm)
         self.opt.step()
         torch._foreach_copy_(self.low, self.master)                  # fp32 -> bf16

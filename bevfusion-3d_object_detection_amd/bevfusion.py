@@ -67,6 +67,7 @@ class BEVFusion(nn.Module):
         self.static_lidar = os.environ.get("BFHIP_STATIC_LIDAR", "0") == "1"
         self._voxel_cap = None
         self._voxel_monitor = None
+        self._voxel_status = None  # static capacity mode: device bool, this forward's voxels exceeded the row capacity
 
     # ------------------------------------------------------------------ LiDAR branch
     @torch.no_grad()
@@ -148,6 +149,7 @@ class BEVFusion(nn.Module):
         _lib.call("bfhip_voxel_compact_mean", voxels.data_ptr(), coors.data_ptr(), num.data_ptr(), counts.data_ptr(), B, max_voxels,
                   P, Fdim, cap, feats.data_ptr(), coords.data_ptr(), n_total.data_ptr(), _lib.stream_of(feats))
         self._voxel_monitor.submit(n_total)
+        self._voxel_status = n_total[1] > cap
         return feats, coords, n_total[0:1]
 
     def _static_lidar_ready(self):
@@ -162,6 +164,7 @@ class BEVFusion(nn.Module):
             with torch.autocast("cuda", enabled=False):
                 feats, coords, n_valid = self.voxelize_static([p.float() for p in points])
             return self.pts_middle_encoder(feats, coords, len(points), n_valid=n_valid)
+        self._voxel_status = None
         with torch.autocast("cuda", enabled=False):  # fp32 island = voxelization only, as the reference (:201-206)
             points = [p.float() for p in points]
             feats, coords, sizes = self.voxelize(points)
@@ -263,7 +266,28 @@ class BEVFusion(nn.Module):
         from .head_targets import PackedGT
         metas = None if isinstance(batch_data_samples, PackedGT) else [getattr(d, "metainfo", None) for d in batch_data_samples]
         feats, _ = self.extract_feat(batch_inputs_dict, metas)
-        return dict(self.bbox_head.loss(feats, batch_data_samples))
+        losses = dict(self.bbox_head.loss(feats, batch_data_samples))
+        status = self.capacity_status()
+        if status is not None:
+            # static capacity mode: a frame that overflowed a row capacity was computed on truncated rows (detected on the
+            # host only one forward later).  The step must not train on that BEV map: its losses become NaN on the device
+            # (no host read), and the optimizers of this package skip a step whose gradient norm is not finite (amp.py)
+            poison = torch.where(status, float("nan"), 0.0)
+            for k in losses:
+                if "loss" in k:
+                    losses[k] = losses[k] + poison
+        return losses
+
+    def capacity_status(self):
+        """Device bool (or None outside static capacity mode): the last forward of the LiDAR branch exceeded a row capacity."""
+        enc = self.pts_middle_encoder
+        flags = [f for f in (self._voxel_status, getattr(enc, "capacity_status", None)) if f is not None]
+        if not flags:
+            return None
+        main = torch.cuda.current_stream(flags[0].device)
+        for f in flags:
+            f.record_stream(main)  # produced on the LiDAR side stream, consumed behind main.wait_stream(side)
+        return flags[0] if len(flags) == 1 else flags[0] | flags[1]
 
     def predict(self, batch_inputs_dict, batch_data_samples=None, **kwargs):
         """BF/bevfusion.py:257-303 without the Det3DDataSample packaging: one dict of boxes/scores/labels per sample."""
@@ -273,8 +297,33 @@ class BEVFusion(nn.Module):
 
     @staticmethod
     def parse_losses(losses):
-        """BF/bevfusion.py:83-120 minus the logging all-reduce: total = sum of every entry whose key contains 'loss'."""
-        return sum(v.mean() for k, v in losses.items() if "loss" in k)
+        """BF/bevfusion.py:88-121: -> (loss, log_vars).  Every entry is reduced to its mean (lists of tensors: sum of the
+        means), `loss` = sum of the entries whose key contains 'loss', `log_vars` additionally carries that total under
+        'loss'.  With an initialised process group every logged scalar is all-reduced and divided by the world size, as the
+        reference does for logging (:114-119; the returned `loss` itself stays local, gradients are averaged by the
+        gradient exchange).  log_vars values are 0-d DEVICE tensors: the reference calls `.item()` on each (a host read per
+        entry per step, :119) -- left to the caller's logger."""
+        from collections import OrderedDict
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if torch.is_tensor(value):
+                log_vars[name] = value.mean()
+            elif isinstance(value, (list, tuple)):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError("%s is not a tensor or list of tensors" % name)
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["loss"] = loss
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # ONE collective for all logged scalars instead of the reference's one per entry
+            flat = torch.stack([v.detach().float() for v in log_vars.values()])
+            dist.all_reduce(flat)
+            flat = flat / dist.get_world_size()
+            logged = OrderedDict((k, flat[i]) for i, k in enumerate(log_vars))
+        else:
+            logged = OrderedDict((k, v.detach()) for k, v in log_vars.items())
+        return loss, logged
 
 
 def nuscenes_config(camera=True, lidar=True):

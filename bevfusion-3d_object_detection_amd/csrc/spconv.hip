@@ -306,7 +306,13 @@ __global__ __launch_bounds__(256) void sparse_pairs_kernel(const int4 *__restric
       long long cell = (((long long)c.x * G.out0 + ox) * G.out1 + oy) * G.out2 + oz;
       unsigned wbits = bitmap[cell >> 5];
       o = word_prefix[cell >> 5] + __popc(wbits & ((1u << (cell & 31)) - 1u));
-      if (o < ld_out) pair_fwd[(size_t)k * ld_out + o] = n;
+      // ld_out may be a capacity (static capacity mode): an output row beyond it does not exist in any buffer of this
+      // layer, so the pair is dropped on BOTH sides (an unclamped pair_bwd entry would make the data gradient gather
+      // grad_out rows past the buffer)
+      // atomicMax over the -1 pre-fill instead of a plain store: with duplicate input coordinates (malformed input; the
+      // reference's own encoder test feeds them) several rows claim one slot, and the HIGHEST row wins deterministically
+      if (o < ld_out) atomicMax(&pair_fwd[(size_t)k * ld_out + o], n);
+      else { o = -1; ok = false; }
     }
     pair_bwd[t] = o;
   }
@@ -347,8 +353,12 @@ __global__ __launch_bounds__(1024) void sparse_pairs_rows_kernel(const int4 *__r
       const long long cell = base + oz / G.s2;
       const unsigned wbits = bitmap[cell >> 5];
       o = word_prefix[cell >> 5] + __popc(wbits & ((1u << (cell & 31)) - 1u));
-      if (o < ld_out) pair_fwd[(size_t)k * ld_out + o] = n;
-      bits |= 1u << (k & 31);
+      if (o < ld_out) {  // beyond a static capacity: the pair is dropped on both sides (see sparse_pairs_kernel)
+        atomicMax(&pair_fwd[(size_t)k * ld_out + o], n);  // duplicates: highest row wins (see sparse_pairs_kernel)
+        bits |= 1u << (k & 31);
+      } else {
+        o = -1;
+      }
     }
     if (n < N) pair_bwd[(size_t)k * N + n] = o;
   }
@@ -1835,6 +1845,62 @@ BFHIP_EXPORT int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, 
   prof_end(&ps);
   if (e != hipSuccess) { set_error("rulebook_sort_rows: sort: %s", hipGetErrorString(e)); return BFHIP_E_LAUNCH; }
   return check_launch("rulebook_sort_rows");
+}
+
+// Debug guard of the gather kernels' operands (they dereference pairs[k*ld + perm[i]] and in + pairs[..]*Kdim unchecked):
+// status[0] = pair entries outside [-1, n_src), status[1] = perm entries outside [0, n_rows), status[2] = rows that do
+// not occur exactly once in perm, status[3] = rows whose row_mask disagrees with the table.  `seen` = i32[n_rows], zeroed.
+namespace {
+__global__ __launch_bounds__(256) void rulebook_validate_kernel(const int *__restrict__ pairs, int ld, int KV, int n_rows,
+                                                                int n_src, const int *__restrict__ perm,
+                                                                const unsigned *__restrict__ row_mask,
+                                                                int *__restrict__ seen, int *__restrict__ status) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_rows) return;
+  unsigned m = 0u;
+  int bad = 0;
+  for (int k = 0; k < KV; ++k) {
+    const int v = pairs[(size_t)k * ld + n];
+    if (v < -1 || v >= n_src) ++bad;
+    if (v >= 0 && k < 32) m |= 1u << k;
+  }
+  if (bad) atomicAdd(&status[0], bad);
+  if (row_mask && KV <= 32 && row_mask[n] != m) atomicAdd(&status[3], 1);
+  if (perm) {
+    const int p = perm[n];
+    if (p < 0 || p >= n_rows) atomicAdd(&status[1], 1);
+    else atomicAdd(&seen[p], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void rulebook_validate_perm_kernel(const int *__restrict__ seen, int n_rows,
+                                                                     int *__restrict__ status) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < n_rows && seen[n] != 1) atomicAdd(&status[2], 1);
+}
+}  // namespace
+
+BFHIP_EXPORT size_t bfhip_rulebook_validate_workspace_bytes(int n_rows) {
+  return align_up((size_t)(n_rows > 0 ? n_rows : 1) * sizeof(int), 256) + 256;
+}
+
+BFHIP_EXPORT int bfhip_rulebook_validate(const int32_t *pairs, int ld, int KV, int n_rows, int n_src, const int32_t *perm,
+                                         const uint32_t *row_mask, int32_t *status_dev, void *workspace,
+                                         size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BFHIP_REQUIRE(KV > 0 && KV <= 64 && n_rows >= 0 && ld >= n_rows && n_src >= 0, "rulebook_validate: bad sizes");
+  BFHIP_REQUIRE(status_dev, "rulebook_validate: status_dev is null");
+  if (hipMemsetAsync(status_dev, 0, 4 * sizeof(int), stream) != hipSuccess) return check_launch("rulebook_validate memset");
+  if (n_rows == 0) return BFHIP_OK;
+  BFHIP_REQUIRE(pairs, "rulebook_validate: null pointer");
+  if (workspace_bytes < bfhip_rulebook_validate_workspace_bytes(n_rows) || !workspace) { set_error("rulebook_validate: workspace too small"); return BFHIP_E_WORKSPACE; }
+  int *seen = (int *)workspace;
+  if (perm && hipMemsetAsync(seen, 0, (size_t)n_rows * sizeof(int), stream) != hipSuccess) return check_launch("rulebook_validate memset");
+  hipLaunchKernelGGL(rulebook_validate_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, stream, pairs, ld, KV, n_rows, n_src,
+                     perm, row_mask, seen, status_dev);
+  if (perm)
+    hipLaunchKernelGGL(rulebook_validate_perm_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, stream, seen, n_rows, status_dev);
+  return check_launch("rulebook_validate");
 }
 
 // Gather-GEMM: out[n_rows, Ndim] = sum_k M_k . in[pairs[k][row]]  with M_k derived from W (Cout,KV,Cin):

@@ -68,6 +68,9 @@ class FlatGradAllReduce:
         self.world = dist.get_world_size(group)
         self.exchange = exchange or os.environ.get("BFHIP_GRAD_EXCHANGE", "a2a")
         assert self.exchange in ("a2a", "allreduce_fp32", "allreduce_bf16"), self.exchange
+        params = list(params)
+        if self.exchange == "a2a" and self.world > 1:
+            self.exchange = self._agree_on_exchange(next((p for p in params if p.requires_grad and p.dtype in _LOW), None))
         self.groups = []
         self._scratch = {}
         for dtype, ps in _by_dtype([p for p in params if p.requires_grad]).items():
@@ -82,6 +85,32 @@ class FlatGradAllReduce:
                 views.append(seg.as_strided(p.size(), p.stride()) if _dense(p) else seg.view_as(p))
                 off += p.numel()
             self.groups.append((ps, flat, views))
+
+    def _agree_on_exchange(self, like):
+        """Decided ONCE, here, by all ranks together -- never in the hot path: a collective that fails on one rank while its
+        peers are already inside it cannot be recovered from by falling back locally.  Every rank tries the all-to-all on a
+        W-element tensor of the gradients' type and waits for it; the ranks then all-reduce(MIN) their verdicts, so either all
+        of them use the direct reduce-scatter / all-gather exchange or all of them the widened fp32 all-reduce."""
+        if like is None:
+            return "a2a"
+        ok = 1
+        try:
+            probe = torch.ones(self.world, dtype=like.dtype, device=like.device)
+            out = torch.empty_like(probe)
+            dist.all_to_all_single(out, probe, group=self.group)
+            if like.is_cuda:
+                torch.cuda.synchronize(like.device)
+            ok = int(bool((out.float() == 1).all()))
+        except RuntimeError:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=like.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            return "a2a"
+        import warnings
+        warnings.warn("gradient exchange: all_to_all_single of %s is not usable on backend %s; every rank uses the fp32 "
+                      "all-reduce" % (like.dtype, dist.get_backend(self.group)))
+        return "allreduce_fp32"
 
     def bytes_per_step(self):
         return sum(flat.numel() * flat.element_size() for _, flat, _ in self.groups)
@@ -107,20 +136,13 @@ class FlatGradAllReduce:
             if W > 1:
                 wide.mul_(1.0 / W)
             flat.copy_(wide)
-        elif W == 1:
+        elif W == 1 and os.environ.get("BFHIP_GRAD_A2A_AT_W1", "0") != "1":
             dist.all_reduce(flat, group=self.group)  # keeps the collective in the timed path of a 1-rank rehearsal
+            # (BFHIP_GRAD_A2A_AT_W1=1: the all-to-all / all-gather pair below runs even with one rank -- the 1-rank RCCL test)
         else:
             shard = flat.numel() // W
             recv = self._buf("recv", flat)
-            try:
-                dist.all_to_all_single(recv, flat, group=self.group)       # recv[r] = rank r's copy of MY shard
-            except RuntimeError as err:
-                # a backend without all-to-all for this tensor type (every rank fails alike, before any data moved): the
-                # widened all-reduce gives the same fp32 accumulation at twice the wire bytes
-                import warnings
-                warnings.warn("gradient exchange: all_to_all_single unavailable (%s); using the fp32 all-reduce" % err)
-                self.exchange = "allreduce_fp32"
-                return self._mean_over_ranks(flat)
+            dist.all_to_all_single(recv, flat, group=self.group)           # recv[r] = rank r's copy of MY shard
             mine = self._buf("mine", flat, numel=shard)
             acc = self._buf("acc", flat, numel=shard, dtype=torch.float32)
             torch.sum(recv.view(W, shard), dim=0, dtype=torch.float32, out=acc)

@@ -107,6 +107,11 @@ class BEVFusionSparseEncoder(nn.Module):
         self.static_caps = None
         self._monitor = CapacityMonitor()
         self.overflowed = False
+        # static capacity mode: device bool, True when THIS forward's strided layers produced more rows than their capacities
+        # (rows beyond a capacity are dropped from the rulebooks on both sides, so the BEV map of that step is the truncated
+        # problem's: BEVFusion.loss poisons the step's losses with it instead of training on that map)
+        self.capacity_status = None
+        self._caps_dev = (None, None)
         first_order = ("conv",) if order[0] != "conv" else order  # pre-activation variant keeps a bare first conv
         self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
                                                  indice_key="subm1", conv_type="SubMConv3d", order=first_order)
@@ -175,7 +180,14 @@ class BEVFusionSparseEncoder(nn.Module):
             x.indice_dict["_strided_plans"] = plans
             if true_counts is not None:
                 self._monitor.submit(true_counts)
+                key = tuple(self.static_caps)
+                if self._caps_dev[0] != key:  # host list -> device, once per capacity change (a plain H2D copy, no read)
+                    self._caps_dev = (key, torch.tensor(key[:true_counts.numel()], dtype=torch.int32, device=coors.device))
+                self.capacity_status = (true_counts > self._caps_dev[1]).any()
+            else:
+                self.capacity_status = None
         elif self.presize_rulebooks and coors.is_cuda:
+            self.capacity_status = None
             # all strided layers' output counts in ONE host read (instead of one per layer)
             chain = [m for m in self.modules() if isinstance(m, SparseConv3d)]  # registration order = execution order
             x.indice_dict["_strided_plans"] = prepare_strided_rulebooks(

@@ -294,9 +294,32 @@ def _io16_ok(weight, transpose):
     return _bf16_ok(weight, transpose) and kdim % 8 == 0 and ndim % 8 == 0
 
 
+# Debug guard (DESIGN.md section 6, the round-2 aperture violation): the gather kernels trust pairs / perm / row_mask.  With
+# BFHIP_SPCONV_VALIDATE=1 every gather launch is preceded by bfhip_rulebook_validate and a HOST READ of its four counters.
+VALIDATE = os.environ.get("BFHIP_SPCONV_VALIDATE", "0") == "1"
+
+
+def validate_rulebook(pairs, n_rows, n_src, perm=None, row_mask=None):
+    """[bad pair entries, perm entries out of range, rows not exactly once in perm, row-mask mismatches] (host list; syncs)."""
+    lib = _lib.load()
+    dev = pairs.device
+    status = torch.empty(4, dtype=torch.int32, device=dev)
+    ws = _workspace(dev, lib.bfhip_rulebook_validate_workspace_bytes(n_rows), "validate")
+    with torch.cuda.device(dev):
+        rc = lib.bfhip_rulebook_validate(_lib.ptr(pairs), pairs.shape[1], pairs.shape[0], n_rows, n_src, _lib.ptr(perm),
+                                         _lib.ptr(row_mask), _lib.ptr(status), _lib.ptr(ws), ws.numel(), _lib.stream_of(pairs))
+    _lib.check(rc, "rulebook_validate")
+    return status.tolist()
+
+
 def _gemm(inp, weight, pairs, n_rows, transpose, flip, perm=None, row_mask=None, bf16=False, io16=False):
     cout, cin = weight.shape[0], weight.shape[-1]
     kv = pairs.shape[0]
+    if VALIDATE:
+        bad = validate_rulebook(pairs, n_rows, inp.shape[0], perm, row_mask)
+        if any(bad):
+            raise RuntimeError("spconv gather operands out of range: [pairs, perm range, perm multiplicity, masks] = %s "
+                               "(n_rows %d, ld %d, n_src %d)" % (bad, n_rows, pairs.shape[1], inp.shape[0]))
     out = torch.empty((n_rows, cin if transpose else cout), dtype=torch.bfloat16 if io16 else torch.float32,
                       device=inp.device)
     lib = _lib.load()

@@ -208,6 +208,10 @@ int bfhip_lift_splat_bwd(const void *out_grad, int grad_bf16 /* out_grad is bf16
  *           pair_fwd i32[KV,n_out], pair_bwd i32[KV,N]; the number of pairs is sum(counts_dev[1..64])
  *           (counts_dev is i32[65]; rulebook_subm's n_pairs_dev is i32[64], same convention: 64 spread
  *           counters, because one hot word serialises the atomics).
+ * duplicate input coordinates (never produced by the voxelizers; the reference's own encoder test feeds them,
+ *           tests/test_models/test_middle_encoders/test_sparse_encoders.py:22-25, where spconv's result is whichever
+ *           row its hash insert kept): every duplicate stays a row; a neighbour lookup resolves a coordinate to its LOWEST
+ *           row (SubM table) / a strided output takes the HIGHEST row per (offset, output) slot -- deterministic both.
  * gemm    : out[n_rows, Ndim] = sum_k M_k . in[pairs[k][row]];  transpose=0 forward (M_k = W[:,k,:]^T),
  *           transpose=1 dgrad (M_k = W[:,k',:], k' = KV-1-k when flip else k; flip=1 lets a SubM layer
  *           reuse pair_fwd as its backward table).  Exact-fp32 MFMA, deterministic, no atomics.
@@ -253,6 +257,15 @@ int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *
 size_t bfhip_rulebook_sort_rows_workspace_bytes(int n_rows, int KV);
 int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, int n_rows, uint32_t *row_mask,
                              int32_t *perm, void *workspace, size_t workspace_bytes, void *stream);
+/* Debug guard: the gather kernels below dereference pairs[k*ld + perm[i]] and in + pairs[..]*K unchecked (an index that is
+ * out of range is a memory-aperture fault).  Counts into status_dev i32[4]: [0] pair entries outside
+ * [-1, n_src), [1] perm entries outside [0, n_rows), [2] rows not occurring exactly once in perm, [3] rows whose row_mask
+ * disagrees with the table.  perm / row_mask optional.  The Python host runs it before every gather launch under
+ * BFHIP_SPCONV_VALIDATE=1 and in the parity tests; it is not part of the timed path. */
+size_t bfhip_rulebook_validate_workspace_bytes(int n_rows);
+int bfhip_rulebook_validate(const int32_t *pairs, int ld, int KV, int n_rows, int n_src, const int32_t *perm,
+                            const uint32_t *row_mask, int32_t *status_dev, void *workspace, size_t workspace_bytes,
+                            void *stream);
 size_t bfhip_spconv_workspace_bytes(int KV, int Cin, int Cout);
 int bfhip_spconv_gemm(const float *in, const float *W, const int32_t *pairs, int ld, int KV,
                       int n_rows, int Cin, int Cout, int transpose, int flip, const int32_t *perm,

@@ -398,7 +398,39 @@ def make_bev_pool_goldens():
     print("bev_pool_ref.npz:", {k: getattr(val, "shape", val) for k, val in out.items()})
 
 
+# --------------------------------------------------------------------------------------- (E)
+def make_real_sweep_goldens():
+    """The one real LiDAR sweep the reference ships (demo/data/nuscenes/*LIDAR_TOP*.pcd.bin: raw float32 [N, 5], read with
+    np.fromfile -- data, not a pickle) -> tests/golden/real_sweep.npz: the points themselves (693 760 B) and the outputs of
+    the REFERENCE's compiled dynamic_voxelize (oracle/_ref) on them at the nuScenes grid.  The reference's hard_voxelize CPU
+    path cannot run this grid (out-of-bounds table, voxelization_cpu.cpp:75,129-130), so the hard-voxelization quantities are
+    DERIVED from the reference's per-point coordinates with the first-come rule of voxelization_cpu.cpp:70-98 in numpy
+    (unique voxels in order of first occurrence, <= 10 points kept per voxel)."""
+    import glob
+    import voxel_layer_ref as v
+    f = glob.glob(os.path.join(REF, "demo", "data", "nuscenes", "*LIDAR_TOP*.pcd.bin"))
+    assert len(f) == 1, f
+    pts = np.fromfile(f[0], dtype=np.float32).reshape(-1, 5)
+    N = synthetic.NUSC
+    dyn = ref_dynamic_voxelize(v, pts, N["voxel_size"], N["point_cloud_range"])
+    inside = dyn[:, 0] >= 0
+    lin = (dyn[:, 0].astype(np.int64) * 1440 + dyn[:, 1]) * 41 + dyn[:, 2]
+    lin_in = lin[inside]
+    uniq, first, counts = np.unique(lin_in, return_index=True, return_counts=True)
+    order = np.argsort(first, kind="stable")            # voxel id = order of the first point (voxelization_cpu.cpp:78-90)
+    hard_coors = dyn[inside][first[order]]
+    hard_num = np.minimum(counts[order], N["max_num_points"]).astype(np.int32)
+    out = {"points": pts, "dyn_coors_sha": sha(dyn), "dyn_coors_sample": dyn[::97].copy(), "n_inside": int(inside.sum()),
+           "n_voxels": int(uniq.size), "hard_coors_sha": sha(hard_coors.astype(np.int32)), "hard_num_sha": sha(hard_num),
+           "hard_coors_head": hard_coors[:64].astype(np.int32), "hard_num_head": hard_num[:64]}
+    np.savez_compressed(os.path.join(HERE, "real_sweep.npz"), **out)
+    print("real_sweep.npz:", {k: (val.shape if hasattr(val, "shape") and val.shape else val) for k, val in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "real_sweep":
+        make_real_sweep_goldens()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "head":
         make_head_goldens()
         sys.exit(0)
@@ -409,3 +441,4 @@ if __name__ == "__main__":
     make_lss_goldens()
     make_head_goldens()
     make_bev_pool_goldens()
+    make_real_sweep_goldens()

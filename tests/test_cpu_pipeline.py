@@ -112,3 +112,27 @@ def test_config0_full_forward_gpu_vs_cpu_pipeline(dev):
     assert x_g[0].shape == x_c[0].shape == (1, 512, 180, 180)
     assert l2(x_g[0].float().cpu(), x_c[0]) < 2e-3
     assert l2(outs_g[0][0]["dense_heatmap"].float().cpu(), outs_c[0][0]["dense_heatmap"]) < 2e-3
+
+
+@pytest.mark.gpu
+def test_view_transform_bf16_conv_stacks_vs_fp32_cpu_pipeline(dev):
+    """The benchmark's default runs the view transform's dense conv stacks (dtransform / depthnet / downsample) in bf16
+    (`DepthLSSTransform.conv_dtype`) where the reference keeps the whole view transform in an fp32 island
+    (BF/bevfusion.py:177); geometry, ranks, softmax inputs' index paths and the pooling's accumulation stay fp32.
+    Against the fp32 CPU pipeline the deviation is bounded by the north star's bf16 tolerance: 1e-2 relative."""
+    torch.manual_seed(0)
+    model = MODELS.build(nuscenes_config()).train()
+    vt = model.view_transform
+    pts, mats, _ = _frame(1)
+    feats = torch.from_numpy(np.random.default_rng(7).standard_normal((1, 6, 256, 32, 88)).astype(np.float32))
+    with torch.no_grad():
+        want = cp.view_transform_forward(copy.deepcopy(vt), feats, pts, mats, exact=True)
+        vt = vt.to(dev)
+        vt.conv_dtype = torch.bfloat16
+        t = {k: torch.from_numpy(v).to(dev) for k, v in mats.items()}
+        got, _ = vt(feats.to(dev).to(torch.bfloat16), [torch.from_numpy(p).to(dev) for p in pts], t["lidar2img"], t["cam2img"],
+                    t["cam2lidar"], t["img_aug_matrix"], t["lidar_aug_matrix"])
+    assert got.shape == want.shape == (1, 80, 180, 180)
+    err = rel_err(got.float().cpu().numpy(), want.numpy())
+    l2 = float((got.float().cpu().double() - want.double()).norm() / want.double().norm())
+    assert err < 1e-2 and l2 < 1e-2, (err, l2)

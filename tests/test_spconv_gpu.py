@@ -627,3 +627,146 @@ def test_static_capacity_lidar_branch_has_no_host_reads(dev):
     want = model.extract_pts_feat(big)
     assert rel_err(got.detach().cpu().numpy(), want.detach().cpu().numpy()) < 1e-5
     del rm_ref
+
+
+def test_reference_encoder_test_with_duplicate_coordinates(dev, sorted_rows, monkeypatch):
+    """The reference's only test at the spconv boundary (tests/test_models/test_middle_encoders/test_sparse_encoders.py:8-28):
+    207 842 rows whose (b, z, y, x) are all randint(0, 4) -- 256 distinct cells, ~800 duplicates each -- through the
+    basicblock encoder; it asserts the output shape [4, 256, 128, 128] only (spconv's values there depend on which duplicate
+    its hash insert kept).  Here: same shape in this fork's (x, y, z) order, every gather operand in range (validator on
+    every launch), finite, and bit-identical across two runs -- duplicate rows all stay rows, a neighbour lookup resolves to
+    the lowest duplicate (SubM) / the highest one per (offset, output) slot (strided), include/bevfusion_hip.h."""
+    from bevfusion_amd import spconv
+    monkeypatch.setattr(spconv, "VALIDATE", True)
+    torch.manual_seed(0)
+    enc = BEVFusionSparseEncoder(in_channels=5, sparse_shape=[1024, 1024, 40], order=("conv", "norm", "act"),
+                                 encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                                 encoder_paddings=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+                                 block_type="basicblock").to(dev)
+    g = torch.Generator().manual_seed(1)
+    voxel_features = torch.rand([207842, 5], generator=g).to(dev)
+    coors = torch.randint(0, 4, [207842, 4], generator=g).to(dev)      # int64, as the reference's test hands it over
+    ret = enc(voxel_features, coors, 4)
+    assert ret.shape == torch.Size([4, 256, 128, 128])
+    assert torch.isfinite(ret).all()
+    ret.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+    g1 = [p.grad.clone() for p in enc.parameters()]
+    for p in enc.parameters():
+        p.grad = None
+    enc2 = BEVFusionSparseEncoder(in_channels=5, sparse_shape=[1024, 1024, 40], order=("conv", "norm", "act"),
+                                  encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                                  encoder_paddings=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+                                  block_type="basicblock").to(dev)
+    enc2.load_state_dict({k: v for k, v in enc.state_dict().items() if "running" not in k and "num_batches" not in k},
+                         strict=False)
+    ret2 = enc2(voxel_features, coors, 4)
+    assert torch.equal(ret, ret2)                                       # deterministic although 800 rows race per cell
+    ret2.square().mean().backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, enc2.parameters()))
+
+
+def test_duplicate_coordinates_semantics_tiny(dev):
+    """Duplicate rows, explicit expectation: SubM neighbour lookups resolve to the LOWEST row of a cell, a strided output slot
+    takes the HIGHEST input row; every duplicate keeps its backward entry."""
+    idx = np.array([[0, 2, 2, 2], [0, 2, 2, 3], [0, 2, 2, 2], [0, 2, 2, 3], [0, 2, 2, 2]], np.int32)
+    t = torch.from_numpy(idx).to(dev)
+    data = build_subm_rulebook(t, 1, [8, 8, 8], [3, 3, 3], [1, 1, 1])
+    pf = data.pair_fwd.cpu().numpy()
+    assert (pf[13] == np.arange(5)).all()                      # centre offset: every row is its own pair
+    assert (pf[14] == np.array([1, -1, 1, -1, 1])).all()       # z + 1 neighbour of cell (2,2,2) = lowest row at (2,2,3)
+    assert (pf[12] == np.array([-1, 0, -1, 0, -1])).all()      # z - 1 neighbour of cell (2,2,3) = lowest row at (2,2,2)
+    d2 = build_sparse_rulebook(t, 1, [8, 8, 8], [1, 1, 1], [1, 1, 1], [0, 0, 0], [1, 1, 1])
+    assert d2.out_indices.cpu().numpy().tolist() == [[0, 2, 2, 2], [0, 2, 2, 3]]
+    assert d2.pair_fwd.cpu().numpy().tolist() == [[4, 3]]      # highest duplicate per output
+    assert d2.pair_bwd.cpu().numpy().tolist() == [[0, 1, 0, 1, 0]]
+
+
+def test_first_forward_at_the_round2_fault_geometry_is_validated(dev, sorted_rows, monkeypatch):
+    """Round 2 lost a GPU to HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in spconv_gemm_lds_kernel<4,1> (fp32 features, row
+    sorting on, the FIRST forward of a process at batch 4 -- DESIGN.md section 6).  That kernel trusts perm / row_mask / pairs;
+    this runs the same geometry (fresh model, no hints, fp32, no autocast, 4 x 40 k points, forward + backward) with
+    bfhip_rulebook_validate in front of every one of the 41 gather launches, and checks that the sorted row order changes no
+    bit of the forward."""
+    from bevfusion_amd import spconv
+    from bevfusion_amd.bevfusion import nuscenes_config
+    from bevfusion_amd.registry import MODELS
+    monkeypatch.setattr(spconv, "VALIDATE", True)
+    torch.manual_seed(0)
+    model = MODELS.build(nuscenes_config(camera=False, lidar=True)).to(dev).train()
+    inp = {"points": [torch.from_numpy(synthetic.lidar_sweep(40000, seed=1000 + i)).to(dev) for i in range(4)]}
+    with torch.no_grad():
+        first = model.extract_pts_feat(inp)                  # what bench.collect_work does first: fp32, no autocast
+    out = model.extract_pts_feat(inp)
+    out.square().mean().backward()
+    enc = model.pts_middle_encoder
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+    monkeypatch.setattr(spconv, "SORT_ROWS", False)
+    model.eval()                                             # same BatchNorm statistics for both orders
+    with torch.no_grad():
+        a = model.extract_pts_feat(inp)
+        monkeypatch.setattr(spconv, "SORT_ROWS", True)
+        b = model.extract_pts_feat(inp)
+    assert torch.equal(a, b) and torch.isfinite(first).all()
+
+
+def test_validator_flags_bad_operands(dev):
+    from bevfusion_amd.spconv import validate_rulebook
+    pairs = torch.tensor([[0, 1, 2, -1], [3, -1, 7, 0]], dtype=torch.int32, device=dev)
+    perm = torch.tensor([3, 2, 1, 0], dtype=torch.int32, device=dev)
+    mask = torch.tensor([3, 1, 3, 2], dtype=torch.int32, device=dev)
+    assert validate_rulebook(pairs, 4, 8, perm, mask) == [0, 0, 0, 0]
+    assert validate_rulebook(pairs, 4, 7, perm, mask) == [1, 0, 0, 0]          # entry 7 with 7 source rows
+    bad_perm = torch.tensor([3, 2, 2, 9], dtype=torch.int32, device=dev)
+    assert validate_rulebook(pairs, 4, 8, bad_perm, mask) == [0, 1, 3, 0]      # 9 out of range; rows 0, 1 missing, 2 twice
+    bad_mask = torch.tensor([3, 1, 3, 0], dtype=torch.int32, device=dev)
+    assert validate_rulebook(pairs, 4, 8, perm, bad_mask) == [0, 0, 0, 1]
+
+
+def test_static_capacity_overflow_is_in_bounds_and_poisons_the_step(dev, monkeypatch):
+    """A frame that overflows the learnt row capacities (static capacity mode): (i) every gather operand of forward AND
+    backward stays in range (rows beyond a capacity are dropped from the rulebooks on both sides -- round 2 kept the
+    unclamped output row in pair_bwd, an out-of-bounds read in the strided data gradient); (ii) gradients are finite;
+    (iii) the device-side status is raised in the same forward (no host read), BEVFusion.loss turns it into NaN losses and
+    the optimizer skips the step: parameters and moments do not change."""
+    from bevfusion_amd import spconv
+    from bevfusion_amd.amp import skip_nonfinite_step
+    from bevfusion_amd.bevfusion import nuscenes_config
+    from bevfusion_amd.registry import MODELS
+    torch.manual_seed(0)
+    model = MODELS.build(nuscenes_config(camera=False, lidar=True)).to(dev).train()
+    enc = model.pts_middle_encoder
+    small = {"points": [torch.from_numpy(synthetic.lidar_sweep(20000, seed=70 + i)).to(dev) for i in range(2)]}
+    big = {"points": [torch.from_numpy(synthetic.lidar_sweep(120000, seed=90 + i)).to(dev) for i in range(2)]}
+    model.static_lidar = False
+    model.extract_pts_feat(small)                            # learns the capacities from the small frames
+    model.static_lidar = True
+    ok = model.extract_pts_feat(small)
+    assert model.capacity_status() is not None and not bool(model.capacity_status())
+    # keep the capacities where they are for this test: the stall-free monitors would grow them one forward later
+    monkeypatch.setattr(enc._monitor, "poll", lambda: None)
+    monkeypatch.setattr(model._voxel_monitor, "poll", lambda: None)
+    monkeypatch.setattr(spconv, "VALIDATE", True)
+    out = model.extract_pts_feat(big)                        # overflows voxel and strided-layer capacities
+    assert bool(model.capacity_status())
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+    assert torch.isfinite(out).all() and out.shape == ok.shape
+    # the poisoned loss: NaN -> non-finite gradient norm -> the fused AdamW leaves everything untouched
+    params = [p for p in enc.parameters()]
+    before = [p.detach().clone() for p in params]
+    opt = torch.optim.AdamW(params, lr=1e-2, fused=True)
+    for p in params:
+        p.grad = None
+    poison = torch.where(model.capacity_status(), float("nan"), 0.0)
+    (model.extract_pts_feat(big).square().mean() + poison).backward()
+    skip_nonfinite_step(opt, torch.nn.utils.clip_grad_norm_(params, 35.0, foreach=True))
+    opt.step()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, params))
+    for p in params:
+        p.grad = None
+    model.extract_pts_feat(small).square().mean().backward()   # a clean frame afterwards trains
+    assert not bool(model.capacity_status())
+    skip_nonfinite_step(opt, torch.nn.utils.clip_grad_norm_(params, 35.0, foreach=True))
+    opt.step()
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, params))

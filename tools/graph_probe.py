@@ -40,12 +40,12 @@ def run(part):
                                          i["lidar_aug_matrix"])[0].float().square().mean()
             elif part.startswith("head"):
                 x = torch.randn(2, 512, 180, 180, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-                out = m.parse_losses(m.bbox_head.loss([x], gts))
+                out = m.parse_losses(m.bbox_head.loss([x], gts))[0]
             elif part == "optimizer":
                 wl._update()
                 return None
             else:
-                out = m.parse_losses(m(wl.inputs, None, gts))
+                out = m.parse_losses(m(wl.inputs, None, gts))[0]
         if part.endswith("bwd") or part == "full_step":
             out.backward()
         if part == "full_step":
