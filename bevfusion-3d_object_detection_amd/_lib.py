@@ -30,9 +30,9 @@ SIGNATURES = {
                                      _c_int, _c_int, _c_vp, _c_sz, _c_vp, _c_vp]),
     "bfhip_bev_plan_workspace_bytes": (_c_sz, [ctypes.c_longlong, ctypes.c_longlong]),
     "bfhip_bev_plan": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [_c_vp] * 3 + [_c_vp] * 11 + [_c_int, _c_vp, _c_sz, _c_vp]),
-    "bfhip_lift_splat_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int] + [_c_vp] * 6 + [_c_int, _c_int, ctypes.c_longlong,
+    "bfhip_lift_splat_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int] + [_c_vp] * 6 + [_c_int, _c_int, ctypes.c_longlong,
                                        _c_vp, _c_int, _c_vp]),
-    "bfhip_lift_splat_bwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 4 +
+    "bfhip_lift_splat_bwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_vp] + [_c_int] * 4 +
                              [_c_vp, _c_int, _c_vp, _c_int, _c_vp]),
     "bfhip_conv_out_shape": (_c_int, [_c_vp] * 6),
     "bfhip_rulebook_subm_workspace_bytes": (_c_sz, [_c_int]),

@@ -377,6 +377,157 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(
   if (active) *(float4 *)(d_feat + (size_t)pp * d_feat_pitch + q * 4) = acc;
 }
 
+// ------------------------------------------------------------------ bf16 feature rows (round 3)
+// Under a bf16 depthnet the C features of a pixel ARE bf16 values (BF/depth_lss.py:467-468 widens them with x.float()); gathering
+// them as stored -- 160-byte rows for C = 80 instead of 320 -- is bit-identical and halves the bytes of the gather this kernel
+// is bound by.  A lane owns EIGHT channels (one 16-byte load per member), cq8 = C / 8 lanes per interval / pixel (10 for
+// C = 80: six intervals per wave instead of three); products and sums are the same fp32 operations in the same order.
+__device__ __forceinline__ void widen8(const uint4 v, float f[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint4 narrow8(const float f[8]) {
+  uint4 v;
+  v.x = rne_bf16_bits(f[0]) | (rne_bf16_bits(f[1]) << 16);
+  v.y = rne_bf16_bits(f[2]) | (rne_bf16_bits(f[3]) << 16);
+  v.z = rne_bf16_bits(f[4]) | (rne_bf16_bits(f[5]) << 16);
+  v.w = rne_bf16_bits(f[6]) | (rne_bf16_bits(f[7]) << 16);
+  return v;
+}
+
+template <bool OUT16>
+__global__ __launch_bounds__(256) void lift_splat_fwd16_kernel(
+    const float *__restrict__ depth, int depth_pitch, const unsigned short *__restrict__ feat, int feat_pitch,
+    const unsigned *__restrict__ pd, const int *__restrict__ starts, const int *__restrict__ lengths,
+    const int *__restrict__ cell_of_interval, const int *__restrict__ counts, const int *__restrict__ order, int mmax,
+    int cq, int groups, void *__restrict__ out_) {
+  const int m = min(mmax, counts[1]);
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long blk = order ? xcd_chunked_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const long long wave = (blk * blockDim.x + threadIdx.x) >> 6;
+  const int g = lane / cq;
+  const int q = lane - g * cq;
+  const long long kp = wave * groups + g;
+  if (g >= groups || kp >= m) return;
+  const long long k = order ? order[kp] : kp;
+  const int s = starts[k];
+  const int len = lengths[k];
+  const unsigned *ppd = pd + s;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int i = 0; i < len; i += kU) {
+    const int rem = len - i;
+    unsigned e[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) e[u] = ppd[i + (u < rem ? u : rem - 1)];
+    float dv[kU];
+    uint4 fv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const unsigned pix = e[u] >> 8, dd = e[u] & 255u;
+      dv[u] = depth[(size_t)pix * depth_pitch + dd];
+      fv[u] = *(const uint4 *)(feat + (size_t)pix * feat_pitch + q * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (u < rem) {
+        float f[8];
+        widen8(fv[u], f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn(dv[u], f[c]));
+      }
+    }
+  }
+  const size_t o = (size_t)cell_of_interval[k] * cq + q;  // in units of 8 channels
+  if (OUT16) {
+    ((uint4 *)out_)[o] = narrow8(acc);
+  } else {
+    ((float4 *)out_)[2 * o] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    ((float4 *)out_)[2 * o + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+// pixel-stationary backward with bf16 feature rows: cq lanes per pixel, 8 channels per lane; d_feat leaves as bf16 (the fp32
+// sum rounded once: what the backward of the reference's x.float() does to it)
+template <bool G16>
+__global__ __launch_bounds__(256) void lift_splat_bwd16_kernel(
+    const void *__restrict__ out_grad_, const float *__restrict__ depth, int depth_pitch,
+    const unsigned short *__restrict__ feat, int feat_pitch, const int *__restrict__ cell_of_point, int P_,
+    int D, int HW, int cq, int groups, float *__restrict__ d_depth, int d_depth_pitch,
+    unsigned short *__restrict__ d_feat, int d_feat_pitch) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long wave = xcd_chunked_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int g = lane / cq;
+  const int q = lane - g * cq;
+  const long long p = wave * groups + g;
+  const bool active = g < groups && p < P_;
+  const long long pp = active ? p : 0;
+  const int cam = (int)(pp / HW), hw = (int)(pp - (long long)cam * HW);
+  const int *cop = cell_of_point + (size_t)cam * D * HW + hw;  // + d*HW
+  float f[8];
+  {
+    const uint4 fr = active ? *(const uint4 *)(feat + (size_t)pp * feat_pitch + q * 8) : make_uint4(0, 0, 0, 0);
+    widen8(fr, f);
+  }
+  const float *dep = depth + (size_t)pp * depth_pitch;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  const int gbase = g * cq;
+  for (int d0 = 0; d0 < D; d0 += kU) {
+    int cell[kU];
+    float dv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int d = d0 + u;
+      cell[u] = (active && d < D) ? cop[(size_t)d * HW] : -1;
+      dv[u] = (active && d < D) ? dep[d] : 0.f;
+    }
+    uint4 g16[kU];
+    float4 g32[kU][2];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (G16) {
+        g16[u] = cell[u] < 0 ? make_uint4(0, 0, 0, 0) : ((const uint4 *)out_grad_)[(size_t)cell[u] * cq + q];
+      } else {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        g32[u][0] = cell[u] < 0 ? z : ((const float4 *)out_grad_)[((size_t)cell[u] * cq + q) * 2];
+        g32[u][1] = cell[u] < 0 ? z : ((const float4 *)out_grad_)[((size_t)cell[u] * cq + q) * 2 + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      float gv[8];
+      if (G16) {
+        widen8(g16[u], gv);
+      } else {
+        gv[0] = g32[u][0].x; gv[1] = g32[u][0].y; gv[2] = g32[u][0].z; gv[3] = g32[u][0].w;
+        gv[4] = g32[u][1].x; gv[5] = g32[u][1].y; gv[6] = g32[u][1].z; gv[7] = g32[u][1].w;
+      }
+      // per-lane partial dot over its 8 channels (ascending), then a fixed-shape tree over the cq lanes
+      float part = __fmul_rn(gv[0], f[0]);
+#pragma unroll
+      for (int c = 1; c < 8; ++c) part = __fadd_rn(part, __fmul_rn(gv[c], f[c]));
+      float hi = __shfl(part, gbase + q + 16);
+      if (q < 16 && q + 16 < cq) part = __fadd_rn(part, hi);
+      for (int o = 8; o > 0; o >>= 1) {
+        float other = __shfl(part, gbase + (q ^ o));
+        bool has = ((q ^ o) < cq) && ((q ^ o) < 16);
+        if (q < 16 && has) part = __fadd_rn(part, other);
+      }
+      const int d = d0 + u;
+      if (active && q == 0 && d < D) d_depth[(size_t)pp * d_depth_pitch + d] = part;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn(dv[u], gv[c]));
+    }
+  }
+  if (active) *(uint4 *)(d_feat + (size_t)pp * d_feat_pitch + q * 8) = narrow8(acc);
+}
+
 inline int key_bits(unsigned max_key) {
   int b = 1;
   while (b < 32 && (max_key >> b) != 0) ++b;
@@ -480,62 +631,82 @@ BFHIP_EXPORT int bfhip_bev_plan(const float *frustum, const float *post_trans,
   return check_launch("bev_plan");
 }
 
-BFHIP_EXPORT int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const float *feat,
+BFHIP_EXPORT int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const void *feat, int feat_bf16,
                                       int feat_pitch, const uint32_t *sorted_pd,
                                       const int32_t *starts, const int32_t *lengths,
                                       const int32_t *cell_of_interval, const int32_t *interval_order,
                                       const int32_t *counts_dev, int mmax, int C, long long out_cells, void *out,
                                       int out_bf16, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  BFHIP_REQUIRE(C > 0 && C % 4 == 0 && C / 4 <= kWave, "lift_splat_fwd: C must be a multiple of 4 and <= 256 (C=%d)", C);
-  BFHIP_REQUIRE(feat_pitch % 4 == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)out % 16) == 0,
-                "lift_splat_fwd: feat/out must be 16-byte aligned with a pitch that is a multiple of 4 floats");
+  const int per_lane = feat_bf16 ? 8 : 4;  // channels per lane = one 16-byte load
+  BFHIP_REQUIRE(C > 0 && C % per_lane == 0 && C / per_lane <= kWave,
+                "lift_splat_fwd: C must be a multiple of %d and <= %d (C=%d)", per_lane, per_lane * kWave, C);
+  BFHIP_REQUIRE(feat_pitch % per_lane == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                "lift_splat_fwd: feat/out must be 16-byte aligned with a pitch that is a multiple of 16 bytes");
   BFHIP_REQUIRE(depth && feat && sorted_pd && starts && lengths && cell_of_interval && counts_dev && out,
                 "lift_splat_fwd: null pointer");
   BFHIP_REQUIRE(mmax > 0 && out_cells > 0, "lift_splat_fwd: bad mmax/out_cells");
   if (hipMemsetAsync(out, 0, (size_t)out_cells * C * (out_bf16 ? 2 : 4), stream) != hipSuccess)
     return check_launch("lift_splat_fwd memset");
-  int cq = C / 4, groups = kWave / cq;
+  int cq = C / per_lane, groups = kWave / cq;
   long long waves = ((long long)mmax + groups - 1) / groups;
   ProfScope ps;
   prof_begin(BFHIP_OP_LIFT_SPLAT_FWD, stream, &ps);
-  if (out_bf16)
+  if (feat_bf16 && out_bf16)
+    hipLaunchKernelGGL(lift_splat_fwd16_kernel<true>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
+                       depth_pitch, (const unsigned short *)feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval,
+                       counts_dev, interval_order, mmax, cq, groups, out);
+  else if (feat_bf16)
+    hipLaunchKernelGGL(lift_splat_fwd16_kernel<false>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
+                       depth_pitch, (const unsigned short *)feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval,
+                       counts_dev, interval_order, mmax, cq, groups, out);
+  else if (out_bf16)
     hipLaunchKernelGGL(lift_splat_fwd_kernel<true>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
-                       depth_pitch, feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
+                       depth_pitch, (const float *)feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
                        interval_order, mmax, cq, groups, out);
   else
     hipLaunchKernelGGL(lift_splat_fwd_kernel<false>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, depth,
-                       depth_pitch, feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
+                       depth_pitch, (const float *)feat, feat_pitch, sorted_pd, starts, lengths, cell_of_interval, counts_dev,
                        interval_order, mmax, cq, groups, out);
   prof_end(&ps);
   return check_launch("lift_splat_fwd");
 }
 
 BFHIP_EXPORT int bfhip_lift_splat_bwd(const void *out_grad, int grad_bf16, const float *depth, int depth_pitch,
-                                      const float *feat, int feat_pitch,
+                                      const void *feat, int feat_bf16, int feat_pitch,
                                       const int32_t *cell_of_point, int num_cams, int D, int HW,
-                                      int C, float *d_depth, int d_depth_pitch, float *d_feat,
+                                      int C, float *d_depth, int d_depth_pitch, void *d_feat,
                                       int d_feat_pitch, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  BFHIP_REQUIRE(C > 0 && C % 4 == 0 && C / 4 <= kWave, "lift_splat_bwd: C must be a multiple of 4 and <= 256 (C=%d)", C);
+  const int per_lane = feat_bf16 ? 8 : 4;
+  BFHIP_REQUIRE(C > 0 && C % per_lane == 0 && C / per_lane <= (feat_bf16 ? 32 : kWave),
+                "lift_splat_bwd: C must be a multiple of %d and <= 256 (C=%d)", per_lane, C);
   BFHIP_REQUIRE(num_cams > 0 && D > 0 && HW > 0, "lift_splat_bwd: bad sizes");
-  BFHIP_REQUIRE(feat_pitch % 4 == 0 && d_feat_pitch % 4 == 0 && ((uintptr_t)feat % 16) == 0 &&
-                    ((uintptr_t)d_feat % 16) == 0 && ((uintptr_t)out_grad % (grad_bf16 ? 8 : 16)) == 0,
-                "lift_splat_bwd: feat/d_feat/out_grad must be 16-byte aligned, pitches multiples of 4 floats");
+  BFHIP_REQUIRE(feat_pitch % per_lane == 0 && d_feat_pitch % per_lane == 0 && ((uintptr_t)feat % 16) == 0 &&
+                    ((uintptr_t)d_feat % 16) == 0 && ((uintptr_t)out_grad % ((grad_bf16 && !feat_bf16) ? 8 : 16)) == 0,
+                "lift_splat_bwd: feat/d_feat/out_grad must be 16-byte aligned, pitches multiples of 16 bytes");
   BFHIP_REQUIRE(out_grad && depth && feat && cell_of_point && d_depth && d_feat, "lift_splat_bwd: null pointer");
   long long npix = (long long)num_cams * HW;
-  int cq = C / 4, groups = kWave / cq;
+  int cq = C / per_lane, groups = kWave / cq;
   long long waves = (npix + groups - 1) / groups;
   ProfScope ps;
   prof_begin(BFHIP_OP_LIFT_SPLAT_BWD, stream, &ps);
-  if (grad_bf16)
+  if (feat_bf16 && grad_bf16)
+    hipLaunchKernelGGL(lift_splat_bwd16_kernel<true>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, out_grad, depth,
+                       depth_pitch, (const unsigned short *)feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth,
+                       d_depth_pitch, (unsigned short *)d_feat, d_feat_pitch);
+  else if (feat_bf16)
+    hipLaunchKernelGGL(lift_splat_bwd16_kernel<false>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, out_grad, depth,
+                       depth_pitch, (const unsigned short *)feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth,
+                       d_depth_pitch, (unsigned short *)d_feat, d_feat_pitch);
+  else if (grad_bf16)
     hipLaunchKernelGGL(lift_splat_bwd_kernel<true>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, out_grad, depth,
-                       depth_pitch, feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth, d_depth_pitch, d_feat,
-                       d_feat_pitch);
+                       depth_pitch, (const float *)feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth,
+                       d_depth_pitch, (float *)d_feat, d_feat_pitch);
   else
     hipLaunchKernelGGL(lift_splat_bwd_kernel<false>, dim3(ceil_div(waves * kWave, 256)), dim3(256), 0, stream, out_grad, depth,
-                       depth_pitch, feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth, d_depth_pitch, d_feat,
-                       d_feat_pitch);
+                       depth_pitch, (const float *)feat, feat_pitch, cell_of_point, (int)npix, D, HW, cq, groups, d_depth,
+                       d_depth_pitch, (float *)d_feat, d_feat_pitch);
   prof_end(&ps);
   return check_launch("lift_splat_bwd");
 }

@@ -34,6 +34,8 @@ from .registry import MODELS
 # default for that reason; on, it frees ~1 GB of Infinity-Cache / HBM traffic per step for whatever runs beside it.
 BF16_BEV_OUT = os.environ.get("BFHIP_LIFT_SPLAT_BF16_OUT", "1") == "1"  # A/B switch for lift_splat_bev's bf16 hand-over
 CAMERA_MAJOR = os.environ.get("BFHIP_LIFT_SPLAT_ORDER", "0") == "1"
+# bf16 feature rows gathered as the bf16 depthnet stored them (bit-identical to widening them first: BF/depth_lss.py:467-468)
+BF16_FEAT = os.environ.get("BFHIP_LIFT_SPLAT_BF16_FEAT", "1") == "1"
 
 
 def _inverse(m):
@@ -108,14 +110,16 @@ class _LiftSplat(torch.autograd.Function):
         # depth [P, D] pixel-major, feat [P, C] pixel-major (any pitch, last dim contiguous); out_dtype bf16: the fp32 sums are
         # rounded once on store (what a consumer's cast would do) and the backward takes the bf16 gradient as it is
         assert depth.dim() == 2 and feat.dim() == 2 and depth.stride(1) == 1 and feat.stride(1) == 1
-        assert depth.dtype == torch.float32 and feat.dtype == torch.float32
+        # feat bf16: the depthnet's bf16 output gathered as stored (same values as the reference's x.float(), half the bytes)
+        assert depth.dtype == torch.float32 and feat.dtype in (torch.float32, torch.bfloat16)
+        f16 = 1 if feat.dtype == torch.bfloat16 else 0
         P, C = feat.shape
         assert P == plan.B * plan.N * plan.HW and depth.shape == (P, plan.D)
         assert out_dtype in (torch.float32, torch.bfloat16)
         out = torch.empty((plan.B, plan.nx[2], plan.nx[0], plan.nx[1], C), dtype=out_dtype, device=feat.device)
         with torch.cuda.device(feat.device):
             rc = _lib.load().bfhip_lift_splat_fwd(
-                _lib.ptr(depth), depth.stride(0), _lib.ptr(feat), feat.stride(0), _lib.ptr(plan.sorted_pd),
+                _lib.ptr(depth), depth.stride(0), _lib.ptr(feat), f16, feat.stride(0), _lib.ptr(plan.sorted_pd),
                 _lib.ptr(plan.starts), _lib.ptr(plan.lengths), _lib.ptr(plan.cell_of_interval), _lib.ptr(plan.interval_order),
                 _lib.ptr(plan.counts), plan.mmax, C, plan.out_cells, _lib.ptr(out), 1 if out_dtype == torch.bfloat16 else 0,
                 _lib.stream_of(feat))
@@ -133,11 +137,11 @@ class _LiftSplat(torch.autograd.Function):
             out_grad = out_grad.float()
         P, C = feat.shape
         d_depth = torch.empty((P, plan.D), dtype=torch.float32, device=feat.device)
-        d_feat = torch.empty((P, C), dtype=torch.float32, device=feat.device)
+        d_feat = torch.empty((P, C), dtype=feat.dtype, device=feat.device)  # bf16 features: bf16 gradient, rounded once
         with torch.cuda.device(feat.device):
             rc = _lib.load().bfhip_lift_splat_bwd(
                 _lib.ptr(out_grad), 1 if out_grad.dtype == torch.bfloat16 else 0, _lib.ptr(depth), depth.stride(0), _lib.ptr(feat),
-                feat.stride(0),
+                1 if feat.dtype == torch.bfloat16 else 0, feat.stride(0),
                 _lib.ptr(plan.cell_of_point), plan.B * plan.N, plan.D, plan.HW, C, _lib.ptr(d_depth), plan.D,
                 _lib.ptr(d_feat), C, _lib.stream_of(feat))
         _lib.check(rc, "lift_splat_bwd")
@@ -145,7 +149,7 @@ class _LiftSplat(torch.autograd.Function):
 
 
 def lift_splat(depth, feat, plan, out_dtype=torch.float32):
-    """depth f32[P,D], feat f32[P,C] (pixel-major) -> BEV f32 (or bf16) [B, nz, nx, ny, C]."""
+    """depth f32[P,D], feat f32 | bf16 [P,C] (pixel-major) -> BEV f32 (or bf16) [B, nz, nx, ny, C]."""
     return _LiftSplat.apply(depth, feat, plan, out_dtype)
 
 
@@ -256,13 +260,18 @@ class BaseViewTransform(nn.Module):
         feat_pm = feat.permute(0, 2, 3, 1).reshape(BN * fH * fW, C)
         if depth_pm.stride(1) != 1:
             depth_pm = depth_pm.contiguous()
-        if feat_pm.stride(1) != 1 or feat_pm.stride(0) % 4 or feat_pm.data_ptr() % 16:
+        # bf16 features (a bf16 depthnet, get_depth_and_feat) are gathered as stored when C allows 16-byte pieces
+        f16 = BF16_FEAT and feat_pm.dtype == torch.bfloat16 and C % 8 == 0
+        if not f16:
+            feat_pm = feat_pm.float()
+        per16 = 16 // feat_pm.element_size()
+        if feat_pm.stride(1) != 1 or feat_pm.stride(0) % per16 or feat_pm.data_ptr() % 16:
             feat_pm = feat_pm.contiguous()
         # with bf16 conv stacks behind it (conv_dtype) the BEV map leaves the kernel in bf16: the downsample convolution's cast
         # and its backward (two 40 MB copies per step) disappear, the values are the ones that cast would have produced
         # (bit-identical model results; step time unchanged within noise: 33.79 vs 33.72 ms over three runs each)
         out_dtype = torch.bfloat16 if (BF16_BEV_OUT and getattr(self, "conv_dtype", None) == torch.bfloat16) else torch.float32
-        out = lift_splat(depth_pm.float(), feat_pm.float(), plan, out_dtype)  # [B, nz, nx, ny, C]
+        out = lift_splat(depth_pm.float(), feat_pm, plan, out_dtype)  # [B, nz, nx, ny, C]
         if out.shape[1] == 1:
             # nz == 1 (every BEVFusion config): [B, nx, ny, C] IS the channels-last memory of [B, C, nx, ny] -> no copy
             # (a reshape, not out[:, 0]: the backward of a select is a zero-fill + copy)
@@ -465,13 +474,18 @@ class DepthLSSTransform(BaseDepthTransform):
             gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
         with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
             x = self.depthnet(torch.cat([self.run_dtransform(d), x], dim=1))
-        x = x.float()
-        depth = x[:, :self.D].softmax(dim=1)
+        # the reference widens the whole [BN, D + C, fH, fW] tensor (x = x.float()).  Same values, less traffic: only the D depth
+        # logits are widened (the softmax runs in fp32); the C feature channels stay as the bf16 convolution stored them and
+        # the fused lift-splat gathers them in that form (lift_splat_bev)
+        feat = x[:, self.D:self.D + self.C]
+        if not (BF16_FEAT and x.dtype == torch.bfloat16):
+            feat = feat.float()
+        depth = x[:, :self.D].float().softmax(dim=1)
         est_depth_distr = depth.permute(0, 2, 3, 1).reshape(B, N, fH, fW, self.D)
         if self.training:
             depth_aux = gt_depth_distr.view(BN, fH, fW, self.D).permute(0, 3, 1, 2)
             depth = depth + (torch.maximum(depth_aux, depth) - depth).detach()  # straight-through (reference :702-706)
-        return depth, x[:, self.D:self.D + self.C], est_depth_distr, gt_depth_distr, counts_3d
+        return depth, feat, est_depth_distr, gt_depth_distr, counts_3d
 
     def get_cam_feats(self, x, d):
         """Materialised outer product + aux outputs (reference :624-727)."""

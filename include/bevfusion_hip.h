@@ -181,17 +181,21 @@ int bfhip_bev_plan(const float *frustum, const float *post_trans, const float *p
  *   out f32[out_cells, C] (out_bf16 = 1: bf16[out_cells, C], the fp32 sums rounded once on store) with
  *   out_cells = B*nx2*nx0*nx1, zero-filled by the call.
  * bwd: d_depth[p,d] = <out_grad[cell(p,d)], feat[p]>, d_feat[p] = sum_d depth[p,d]*out_grad[cell(p,d)]
+ * feat_bf16 = 1: feat is bf16[P, feat_pitch] (pitches in ELEMENTS, C % 8 == 0) -- the depthnet's output as the bf16
+ *   convolution left it (the reference widens it with x.float(), BF/depth_lss.py:467-468: same values); the gathered rows are
+ *   half as long, the arithmetic is unchanged (fp32 products and sums in the same order), and the backward writes d_feat as
+ *   bf16[P, d_feat_pitch] (the fp32 sums rounded once, what the backward of that x.float() does).
  * --------------------------------------------------------------------------------------- */
-int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const float *feat, int feat_pitch,
+int bfhip_lift_splat_fwd(const float *depth, int depth_pitch, const void *feat, int feat_bf16, int feat_pitch,
                          const uint32_t *sorted_pd, const int32_t *starts, const int32_t *lengths,
                          const int32_t *cell_of_interval, const int32_t *interval_order /* may be NULL: rank order */,
                          const int32_t *counts_dev, int mmax, int C, long long out_cells, void *out, int out_bf16,
                          void *stream);
 int bfhip_lift_splat_bwd(const void *out_grad, int grad_bf16 /* out_grad is bf16[out_cells, C] */, const float *depth,
                          int depth_pitch,
-                         const float *feat, int feat_pitch, const int32_t *cell_of_point,
+                         const void *feat, int feat_bf16, int feat_pitch, const int32_t *cell_of_point,
                          int num_cams, int D, int HW, int C, float *d_depth, int d_depth_pitch,
-                         float *d_feat, int d_feat_pitch, void *stream);
+                         void *d_feat, int d_feat_pitch, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * sparse 3-D convolution  (replaces what the reference delegates to spconv 2.x:

@@ -265,3 +265,79 @@ def test_camera_major_interval_order(dev, monkeypatch):
     plan.interval_order = None                                              # rank order
     b = lift_splat(depth, feat, plan)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C", [80, 8, 16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_lift_splat_bf16_feature_rows_are_bit_identical(dev, C, out_dtype):
+    """feat handed over in bf16 (what a bf16 depthnet stores; the reference widens it with x.float(), BF/depth_lss.py:467-468):
+    the forward equals the fp32-feature kernel fed the widened values bit for bit -- and therefore the oracle -- for fp32 and
+    bf16 outputs; d_feat is the fp32 kernel's d_feat rounded once to bf16 (bit for bit), d_depth agrees to the reduction
+    tree's rounding (1e-5 rel: 10 lanes x 8 channels instead of 20 x 4)."""
+    cfg = dict(TINY, out_channels=C)
+    vt = LSSTransform(**cfg).to(dev)
+    B = 2
+    rig = synthetic.camera_rig(batch=B, seed=7, train_aug=True)
+    rig["img_aug_matrix"][..., 0, 0] = rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3], rig["img_aug_matrix"][..., 1, 3] = -8.0, -44.0
+    cal = _calib(vt, rig, dev)
+    plan = vt.make_plan(**cal)
+    fH, fW = cfg["feature_size"]
+    BN, D = B * 6, vt.D
+    depth, feat = _random_depth_feat(dev, BN * fH * fW, D, C, seed=4)
+    feat16 = feat.to(torch.bfloat16)
+    d32, f32 = depth.clone().requires_grad_(True), feat16.float().requires_grad_(True)
+    d16, f16 = depth.clone().requires_grad_(True), feat16.clone().requires_grad_(True)
+    o32 = lift_splat(d32, f32, plan, out_dtype)
+    o16 = lift_splat(d16, f16, plan, out_dtype)
+    assert o16.dtype == out_dtype and torch.equal(o16, o32)
+    if out_dtype == torch.float32:
+        geom, gf, kept, ranks, idx = _oracle_plan(vt, cal, B)
+        starts, lengths = oracle.intervals_from_ranks(ranks)
+        src = np.flatnonzero(kept)[idx].astype(np.int32)
+        d_ref, f_ref = _to_ref_layout(depth, feat16.float(), BN, fH, fW)
+        nx = vt._nx_host
+        want = oracle.lift_splat_fwd(d_ref, f_ref, src, gf, starts, lengths, B, nx[2], nx[0], nx[1])
+        assert np.array_equal(o16.detach().cpu().numpy(), want)
+    og = torch.randn(o32.shape, generator=torch.Generator().manual_seed(3)).to(dev).to(out_dtype)
+    o32.backward(og)
+    o16.backward(og)
+    assert f16.grad.dtype == torch.bfloat16 and torch.equal(f16.grad, f32.grad.to(torch.bfloat16))
+    assert rel_err(d16.grad.cpu().numpy(), d32.grad.cpu().numpy()) < 1e-5
+    # a feature matrix that is a channel slice of a wider bf16 tensor (pitch > C, 16-byte aligned rows) is consumed in place
+    wide = torch.zeros(feat16.shape[0], C + 24, dtype=torch.bfloat16, device=dev)
+    wide[:, 8:8 + C] = feat16
+    o_slice = lift_splat(depth, wide[:, 8:8 + C], plan, out_dtype)
+    assert torch.equal(o_slice, o32.detach())
+
+
+def test_depth_lss_bf16_features_equal_the_widened_path(dev, monkeypatch):
+    """DepthLSSTransform with bf16 conv stacks: handing the feature channels to the lift-splat as bf16 (default) gives the
+    same BEV map and the same input / weight gradients, bit for bit, as widening the whole depthnet output first (the
+    reference's x.float(), BFHIP_LIFT_SPLAT_BF16_FEAT=0)."""
+    from bevfusion_amd import depth_lss
+    cfg = dict(TINY, in_channels=32, out_channels=16, downsample=2)
+    torch.manual_seed(0)
+    vt = DepthLSSTransform(**cfg).to(dev).train()
+    vt.conv_dtype = torch.bfloat16
+    B, N = 2, 6
+    rig = synthetic.camera_rig(batch=B, seed=1, train_aug=True)
+    rig["img_aug_matrix"][..., 0, 0] = rig["img_aug_matrix"][..., 1, 1] = 0.12
+    rig["img_aug_matrix"][..., 0, 3], rig["img_aug_matrix"][..., 1, 3] = -8.0, -44.0
+    t = {k: torch.from_numpy(v).to(dev) for k, v in rig.items()}
+    pts = [torch.from_numpy(synthetic.lidar_sweep(5000, seed=s)).to(dev) for s in (1, 2)]
+    img0 = torch.randn(B, N, 32, 8, 22, device=dev)
+    res = {}
+    state = {k: v.clone() for k, v in vt.state_dict().items()}
+    for flag in (True, False):
+        monkeypatch.setattr(depth_lss, "BF16_FEAT", flag)
+        vt.load_state_dict(state)
+        for p in vt.parameters():
+            p.grad = None
+        img = img0.clone().requires_grad_(True)
+        x, depth_loss = vt(img, pts, t["lidar2image"], t["camera_intrinsics"], t["camera2lidar"], t["img_aug_matrix"],
+                           t["lidar_aug_matrix"], None)
+        (x.float().square().mean() + depth_loss).backward()
+        res[flag] = (x.detach().clone(), img.grad.clone(), vt.depthnet[0].weight.grad.clone())
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
