@@ -56,7 +56,8 @@ DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd
 # `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side stream off
 # (one queue, nothing beside them) -- the number a rocprofv3 kernel trace reproduces.
 LIDAR_OPS = ("hard_voxelize", "spconv_fwd", "spconv_bwd", "spconv_wgrad", "spconv_wgrad_main", "rulebook")
-ISOLATED_STEPS = int(os.environ.get("BENCH_ISOLATED_STEPS", "5"))
+NO_WORK = os.environ.get("BENCH_NO_WORK") == "1"  # counter passes under rocprofv3: warm-up + timed steps only, nothing else
+ISOLATED_STEPS = 0 if NO_WORK else int(os.environ.get("BENCH_ISOLATED_STEPS", "5"))
 CPU_REPEATS = max(1, int(os.environ.get("BENCH_CPU_REPEATS", "3")))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
 # dense matrix-core peaks (MI355X_MICROARCH.md): bf16 v_mfma_f32_32x32x16_bf16 / fp32-input v_mfma_f32_16x16x4_f32
@@ -654,7 +655,7 @@ def main():
         wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=world > 1 or force_ddp, local_rank=local_rank)
         # BENCH_NO_WORK=1 (counter passes under rocprofv3): no instrumented extra forward, so every kernel family runs exactly
         # warm-up + steps times
-        work = {} if os.environ.get("BENCH_NO_WORK") == "1" else wl.collect_work()
+        work = {} if NO_WORK else wl.collect_work()
     else:
         wl = cls(dev, args.batch, args.points, seed_base=100 * rank)
         work = {"bev_pool_fwd": dict(bound="hbm", bytes=wl.dominant_bytes())}
@@ -822,7 +823,7 @@ def main():
             line["data"] = "synthetic (CPU plumbing rehearsal, not a performance number)"
             line["config"]["grad_fingerprint"] = wl.grad_fingerprint()
         if (world == 1 and not cpu_mode and args.workload == "full" and not args.vt_fp32 and getattr(wl, "vt_bf16", False)
-                and os.environ.get("BENCH_REFERENCE_NUMERICS", "1") == "1"):
+                and os.environ.get("BENCH_REFERENCE_NUMERICS", "1") == "1" and not NO_WORK):
             # the same step with the view transform's conv stacks in fp32 with fp32 weights = the reference's fp32 island
             # (BF/bevfusion.py:177): a second timed region of the same K steps in the same invocation, so that the driver's
             # line carries both numbers (`value` stays the bf16-conv-stack configuration BASELINE configs[3] names)

@@ -271,11 +271,12 @@ class BEVFusion(nn.Module):
         if status is not None:
             # static capacity mode: a frame that overflowed a row capacity was computed on truncated rows (detected on the
             # host only one forward later).  The step must not train on that BEV map: its losses become NaN on the device
-            # (no host read), and the optimizers of this package skip a step whose gradient norm is not finite (amp.py)
-            poison = torch.where(status, float("nan"), 0.0)
+            # (no host read) -- multiplied in, so that every gradient is NaN as well -- and the optimizers of this package
+            # skip a step whose gradient norm is not finite (amp.skip_nonfinite_step)
+            poison = torch.where(status, float("nan"), 1.0)
             for k in losses:
                 if "loss" in k:
-                    losses[k] = losses[k] + poison
+                    losses[k] = losses[k] * poison
         return losses
 
     def capacity_status(self):

@@ -535,10 +535,12 @@ class BEVFusionHead(nn.Module):
         loss_dict["matched_ious"] = matched_ious
         # an invalid matching cost (NaN / inf) leaves every query unmatched: poison the losses instead of training on
         # background-only targets with the wrong normaliser (the reference raises from scipy at this point)
-        poison = torch.where(self.assignment_status.ne(0).any(), float("nan"), 0.0)
+        # MULTIPLIED in (x * nan), not added: the gradient of every parameter then is NaN too, so the step is not only visibly
+        # invalid but is skipped by the optimizers of this package (amp.skip_nonfinite_step) instead of being applied
+        poison = torch.where(self.assignment_status.ne(0).any(), float("nan"), 1.0)
         for k in loss_dict:
             if "loss" in k:
-                loss_dict[k] = loss_dict[k] + poison
+                loss_dict[k] = loss_dict[k] * poison
         return loss_dict
 
     def check_assignment(self):

@@ -148,6 +148,27 @@ class _LiftSplat(torch.autograd.Function):
         return d_depth, d_feat, None, None
 
 
+class _SplitDepthFeat(torch.autograd.Function):
+    """x bf16[P, >= D + C] (the depthnet's pixel-major output) -> (depth logits f32[P, D], features bf16[P, C], both contiguous):
+    two strided copies forward, two strided copies into ONE bf16 gradient backward -- instead of widening all D + C channels,
+    slicing, re-packing the feature slice and, in the backward, two zero-padded slice gradients plus their sum."""
+
+    @staticmethod
+    def forward(ctx, x, D, C):
+        ctx.shape, ctx.D, ctx.C = x.shape, D, C
+        return x[:, :D].float(), x[:, D:D + C].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_logits, g_feat):
+        D, C = ctx.D, ctx.C
+        dx = torch.empty(ctx.shape, dtype=torch.bfloat16, device=g_logits.device)
+        dx[:, :D].copy_(g_logits)          # fp32 -> bf16, rounded once (what the backward of x.float() does)
+        dx[:, D:D + C].copy_(g_feat)
+        if ctx.shape[1] > D + C:
+            dx[:, D + C:].zero_()
+        return dx, None, None
+
+
 def lift_splat(depth, feat, plan, out_dtype=torch.float32):
     """depth f32[P,D], feat f32 | bf16 [P,C] (pixel-major) -> BEV f32 (or bf16) [B, nz, nx, ny, C]."""
     return _LiftSplat.apply(depth, feat, plan, out_dtype)
@@ -474,13 +495,17 @@ class DepthLSSTransform(BaseDepthTransform):
             gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
         with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
             x = self.depthnet(torch.cat([self.run_dtransform(d), x], dim=1))
-        # the reference widens the whole [BN, D + C, fH, fW] tensor (x = x.float()).  Same values, less traffic: only the D depth
-        # logits are widened (the softmax runs in fp32); the C feature channels stay as the bf16 convolution stored them and
-        # the fused lift-splat gathers them in that form (lift_splat_bev)
-        feat = x[:, self.D:self.D + self.C]
-        if not (BF16_FEAT and x.dtype == torch.bfloat16):
-            feat = feat.float()
-        depth = x[:, :self.D].float().softmax(dim=1)
+        if BF16_FEAT and x.dtype == torch.bfloat16 and x.is_cuda and self.C % 8 == 0:
+            # the reference widens the whole [BN, D + C, fH, fW] tensor (x = x.float()).  Same values, less traffic: only the D
+            # depth logits are widened (the softmax runs in fp32); the C feature channels stay as the bf16 convolution stored
+            # them and the fused lift-splat gathers them in that form (lift_splat_bev)
+            logits, feat_pm = _SplitDepthFeat.apply(x.permute(0, 2, 3, 1).reshape(BN * fH * fW, x.shape[1]), self.D, self.C)
+            depth = logits.view(BN, fH, fW, self.D).softmax(dim=-1).permute(0, 3, 1, 2)   # [BN, D, fH, fW], channels-last memory
+            feat = feat_pm.view(BN, fH, fW, self.C).permute(0, 3, 1, 2)
+        else:
+            x = x.float()
+            depth = x[:, :self.D].softmax(dim=1)
+            feat = x[:, self.D:self.D + self.C]
         est_depth_distr = depth.permute(0, 2, 3, 1).reshape(B, N, fH, fW, self.D)
         if self.training:
             depth_aux = gt_depth_distr.view(BN, fH, fW, self.D).permute(0, 3, 1, 2)

@@ -754,8 +754,9 @@ def test_static_capacity_overflow_is_in_bounds_and_poisons_the_step(dev, monkeyp
     opt = torch.optim.AdamW(params, lr=1e-2, fused=True)
     for p in params:
         p.grad = None
-    poison = torch.where(model.capacity_status(), float("nan"), 0.0)
-    (model.extract_pts_feat(big).square().mean() + poison).backward()
+    out2 = model.extract_pts_feat(big)
+    poison = torch.where(model.capacity_status(), float("nan"), 1.0)   # what BEVFusion.loss multiplies into every loss entry
+    (out2.square().mean() * poison).backward()
     skip_nonfinite_step(opt, torch.nn.utils.clip_grad_norm_(params, 35.0, foreach=True))
     opt.step()
     assert all(torch.equal(a, p.detach()) for a, p in zip(before, params))

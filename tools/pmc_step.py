@@ -18,7 +18,9 @@ FAMILIES = [
     ("spconv_gemm (fwd + dgrad)", lambda n: "spconv_gemm" in n),
     ("bn2d backward (reduce, finalize, apply)", lambda n: "bn2d_bwd" in n or ("bn2d_finalize" in n and "BwdFin" in n)),
     ("bn2d forward (stats, finalize, apply)", lambda n: "bn2d_" in n),
-    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*true>", n) is not None),
+    # last template argument of conv_igemm_kernel = MODE: 0 forward, 1 data gradient (transposed gather), 2 data gradient of a
+    # strided layer by parity classes (round 2 matched a bool that no longer exists and booked these under the forward)
+    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*, [12]>", n) is not None),
     ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n),
     ("conv2d wgrad (main kernel)", lambda n: "conv_wgrad_kernel" in n),
     ("conv weight transpose", lambda n: "conv_weight_transpose" in n),
@@ -50,7 +52,8 @@ BENCH_OPS = {"spconv_wgrad": ["spconv_wgrad", "wgrad_reduce + offset counts"], "
              "bn2d_fwd": ["bn2d forward (stats, finalize, apply)"], "bn2d_bwd": ["bn2d backward (reduce, finalize, apply)"],
              "conv2d_fwd": ["conv2d forward (conv_igemm)"],
              "conv2d_dgrad": ["conv2d dgrad (conv_igemm, transposed gather)", "conv weight transpose"],
-             "conv2d_wgrad": ["conv2d wgrad (main kernel)"]}
+             "conv2d_wgrad": ["conv2d wgrad (main kernel)"],
+             "spconv_fwd+bwd": ["spconv_gemm (fwd + dgrad)"]}
 # 16-byte-per-lane streaming readers: FETCH_SIZE reports half their bytes on gfx950 (MI355X_MICROARCH.md) -> doubled
 STREAMING = {"bn2d_fwd", "bn2d_bwd"}
 
