@@ -563,6 +563,141 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
   tr_store_slab(slab + (size_t)split * wg.Cout * Ktot, wg.Cout, Ktot, co0, q0, lane, wm, wn, acc);
 }
 
+// Round 3: the same weight gradient on wider tiles with a three-stage ring.  The 128 x 128 kernel above runs two workgroups
+// per CU with ONE 32 KB stage in flight each, issued only after the previous one has landed: ~36 KB in flight per CU on
+// average, 44 GB/s per CU of L2 -> LDS fill (the guide's gather-into-LDS rate with 72 KB in flight is 66-73), MFMA 30 % busy.
+// Here a workgroup owns (PG * 128) dy channels x (PX * 128) K columns -- PG + PX "panels" of 64 pixels x 128 columns per
+// stage, each panel laid out exactly like the tiles above, (2 PG) x (2 PX) waves of 64 x 64 -- and keeps TWO stages in
+// flight behind the one being consumed (wait = vmcnt(pieces of one stage), one barrier per step): <1, 2> and <2, 1> move
+// 3/4 of the operand bytes per flop of the 128 x 128 tile with 96 KB continuously in flight per CU.
+template <int PG, int PX, int STAGES>
+__global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const bf16_t *__restrict__ x,
+                                                                           const bf16_t *__restrict__ dy,
+                                                                           float *__restrict__ slab, WgradGeom wg) {
+  constexpr int W = 4 * PG * PX;            // waves
+  constexpr int GPW = 16 / W;               // 4-row groups of a 64-pixel stage staged by one wave
+  static_assert(GPW >= 1 && GPW * W == 16, "waves must divide the 16 row groups of a stage");
+  constexpr int BP = 64, PANEL = BP * 256;  // one panel: 64 pixels x 128 columns bf16
+  constexpr int SB = (PG + PX) * PANEL;     // bytes of one stage
+  constexpr int PER_STAGE = GPW * (PG + PX);  // DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned *taps = (unsigned *)(smem + STAGES * SB);
+  const ConvGeom &g = wg.c;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles = wg.tiles_co * wg.tiles_k;
+  const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles * wg.splits);
+  const int split = (int)(lb / tiles), tile = (int)(lb - (long long)split * tiles);
+  const int tco = tile / wg.tiles_k, tk = tile - tco * wg.tiles_k;
+  const int co0 = tco * (128 * PG), q0 = tk * (16 * PX);  // first dy channel, first K piece of this tile
+  build_tap_table(taps, g);
+
+  const long long p_begin = (long long)split * wg.rows_per_split;
+  long long p_end = p_begin + wg.rows_per_split;
+  if (p_end > g.M) p_end = g.M;
+  const int nsteps = p_end > p_begin ? (int)((p_end - p_begin + BP - 1) / BP) : 0;
+
+  // staging: one DMA instruction = 4 rows x 256 B of one panel; wave w stages row groups [GPW * w, GPW * (w + 1)) of EVERY panel
+  const int lrow = lane >> 4, lpos = lane & 15;
+  int pn[GPW], poh[GPW], pow_[GPW];
+  long long pm[GPW];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    long long m = p_begin + (GPW * w + i) * 4 + lrow;
+    pm[i] = m;
+    long long mm = m < g.M ? m : 0;
+    int n = (int)(mm / ((long long)g.OH * g.OW));
+    int rem = (int)(mm - (long long)n * g.OH * g.OW);
+    pn[i] = n;
+    poh[i] = rem / g.OW;
+    pow_[i] = rem - poh[i] * g.OW;
+  }
+  __syncthreads();
+
+  // a lane's pieces are fixed for the whole kernel: dy channel block of G panel p / K piece (tap, ci) of X panel p, row group i
+  unsigned xinfo[GPW][PX];
+  bool qok[GPW][PX], cok[GPW][PG];
+  int gco[GPW][PG];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int r = (GPW * w + i) * 4 + lrow;
+    const int c = lpos ^ tr_swz(r);
+#pragma unroll
+    for (int p = 0; p < PG; ++p) {
+      gco[i][p] = co0 + p * 128 + c * 8;
+      cok[i][p] = gco[i][p] < wg.Cout;
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      const int q = q0 + p * 16 + c;
+      qok[i][p] = q < g.nq;
+      xinfo[i][p] = qok[i][p] ? taps[q] : 0u;
+    }
+  }
+  const bf16_t *zsrc = zero_src();
+  auto stage = [&](int buf) {
+    unsigned char *base = smem + buf * SB;
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+      const bool rok = pm[i] < p_end;
+      const int rowoff = ((GPW * w + i) * 4) * 256;
+      const bf16_t *grow = dy + (size_t)pm[i] * wg.ldg;
+#pragma unroll
+      for (int p = 0; p < PG; ++p) glds16((rok && cok[i][p]) ? grow + gco[i][p] : zsrc, base + p * PANEL + rowoff);
+      const int hb = poh[i] * g.stride - g.pad, wb = pow_[i] * g.stride - g.pad;
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        const unsigned info = xinfo[i][p];
+        const int ih = hb + (int)(info >> 24), iw = wb + (int)((info >> 16) & 0xff);
+        const bool ok = rok && qok[i][p] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        const bf16_t *sx = ok ? x + ((size_t)((pn[i] * g.H + ih) * g.W + iw) * g.ldx + (info & 0xffff)) : zsrc;
+        glds16(sx, base + (PG + p) * PANEL + rowoff);
+      }
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+      pm[i] += BP;
+      pow_[i] += BP;
+      while (pow_[i] >= g.OW) { pow_[i] -= g.OW; ++poh[i]; }
+      while (poh[i] >= g.OH) { poh[i] -= g.OH; ++pn[i]; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int wm = w / (2 * PX), wn = w % (2 * PX);
+  const TrAddr ad = tr_addresses(lane, wm & 1, wn & 1);
+  const int offG = (wm >> 1) * PANEL, offX = (PG + (wn >> 1)) * PANEL;
+
+  // prologue: STAGES - 1 stages in flight
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nsteps) {
+      if (s0 > 0) advance();
+      stage(s0);
+    }
+  for (int t = 0; t < nsteps; ++t) {
+    const int buf = t % STAGES;
+    // stage t has landed when at most the younger stages' pieces are outstanding
+    if (STAGES == 3 && t + 1 < nsteps) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+    __syncthreads();
+    if (t + STAGES - 1 < nsteps) { advance(); stage((t + STAGES - 1) % STAGES); }
+    const unsigned char *pS = smem + buf * SB;
+    tr_compute_step(pS + offG, pS + offX, ad, acc);
+  }
+
+  const int Ktot = g.nq * 8;
+  tr_store_slab(slab + (size_t)split * wg.Cout * Ktot, wg.Cout, Ktot, co0, q0, lane, wm, wn, acc);
+}
+
 // ------------------------------------------------------------------------------------------------ sparse weight gradient
 // dW[co][k][ci] = sum over output rows of dout[row][co] * in[pairs[k][row]][ci]  (SubMConv3d / SparseConv3d, spconv's
 // (out, kD, kH, kW, in) weight layout): the dense kernel above with the rulebook as the gather -- column piece q of a tile is
@@ -937,10 +1072,42 @@ static void wgrad_plan(long long M, int Cout, int Ktot, int *splits, long long *
   *rows_per_split = per * 64;
 }
 
+// Tile shape of the weight gradient: 0 = 128 x 128 (conv_wgrad_kernel, two workgroups per CU), 1 = 128 co x 256 k and
+// 2 = 256 co x 128 k (conv_wgrad_wide_kernel, three stages, one 512-thread workgroup per CU).  The wide tiles need K (resp.
+// Cout) beyond one 128-column panel, a tap table that fits beside three 48 KB stages, and enough pixels for >= 6 steps.
+static int wgrad_shape(long long M, int Cout, int Ktot) {
+  static const int wide = [] { const char *e = getenv("BFHIP_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
+  if (!wide || Ktot / 8 > 3584 || M < 64 * 6) return 0;
+  if (Ktot > 128) return 1;
+  if (Cout > 128) return 2;
+  return 0;
+}
+
+static void wgrad_plan_wide(long long M, int Cout, int Ktot, int shape, int *splits, long long *rows_per_split, int *tiles_co,
+                            int *tiles_k) {
+  *tiles_co = ceil_div(Cout, shape == 2 ? 256 : 128);
+  *tiles_k = ceil_div(Ktot, shape == 1 ? 256 : 128);
+  const int tiles = *tiles_co * *tiles_k;
+  long long steps = (M + 63) / 64;
+  const int slots = resident_blocks() / 2;          // one workgroup per CU (3 x 48 KB of LDS), one residency round
+  int want = tiles >= slots ? 1 : slots / tiles;
+  if (want > steps / 6) want = (int)(steps / 6);    // at least 6 steps per workgroup (the ring is 3 deep)
+  if (want < 1) want = 1;
+  long long per = (steps + want - 1) / want;
+  *splits = (int)((steps + per - 1) / per);
+  *rows_per_split = per * 64;
+}
+
+static void wgrad_plan_any(long long M, int Cout, int Ktot, int *shape, int *splits, long long *rps, int *tco, int *tk) {
+  *shape = wgrad_shape(M, Cout, Ktot);
+  if (*shape) wgrad_plan_wide(M, Cout, Ktot, *shape, splits, rps, tco, tk);
+  else wgrad_plan(M, Cout, Ktot, splits, rps, tco, tk);
+}
+
 BFHIP_EXPORT size_t bfhip_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
-  int splits, tco, tk;
+  int shape, splits, tco, tk;
   long long rps;
-  wgrad_plan((long long)N * OH * OW, Cout, KH * KW * Cin, &splits, &rps, &tco, &tk);
+  wgrad_plan_any((long long)N * OH * OW, Cout, KH * KW * Cin, &shape, &splits, &rps, &tco, &tk);
   return align_up((size_t)splits * Cout * KH * KW * Cin * sizeof(float), 256);
 }
 
@@ -963,18 +1130,31 @@ BFHIP_EXPORT int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int 
   g.M = (long long)N * g.OH * g.OW;
   g.Kout = Cout; g.ldw = 0; g.ldy = 0;
   wg.Cout = Cout; wg.ldg = ldg;
-  wgrad_plan(g.M, Cout, KH * KW * Cin, &wg.splits, &wg.rows_per_split, &wg.tiles_co, &wg.tiles_k);
+  int shape;
+  wgrad_plan_any(g.M, Cout, KH * KW * Cin, &shape, &wg.splits, &wg.rows_per_split, &wg.tiles_co, &wg.tiles_k);
   BFHIP_REQUIRE(workspace_bytes >= bfhip_conv2d_wgrad_workspace_bytes(N, g.OH, g.OW, Cin, Cout, KH, KW), "conv2d_wgrad: workspace too small");
-  const size_t lds = (size_t)4 * 64 * 256 + (size_t)g.nq * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2);
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_wide_kernel<1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_wide_kernel<2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   ProfScope ps;
   prof_begin(BFHIP_OP_CONV2D_WGRAD, s, &ps);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)wg.tiles_co * wg.tiles_k * wg.splits)), dim3(256), lds, s,
-                     (const bf16_t *)x, (const bf16_t *)dy, (float *)workspace, wg);
+  const dim3 grid((unsigned)((long long)wg.tiles_co * wg.tiles_k * wg.splits));
+  if (shape == 0) {
+    const size_t lds = (size_t)4 * 64 * 256 + (size_t)g.nq * 4;
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), lds, s, (const bf16_t *)x, (const bf16_t *)dy, (float *)workspace, wg);
+  } else {
+    const size_t lds = (size_t)3 * 3 * 64 * 256 + (size_t)g.nq * 4;
+    if (shape == 1)
+      hipLaunchKernelGGL((conv_wgrad_wide_kernel<1, 2, 3>), grid, dim3(512), lds, s, (const bf16_t *)x, (const bf16_t *)dy,
+                         (float *)workspace, wg);
+    else
+      hipLaunchKernelGGL((conv_wgrad_wide_kernel<2, 1, 3>), grid, dim3(512), lds, s, (const bf16_t *)x, (const bf16_t *)dy,
+                         (float *)workspace, wg);
+  }
   const long long total = (long long)Cout * KH * KW * Cin;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(total, 1024)), dim3(256), 0, s, (const float *)workspace, wg.splits,
                      total, dw, dw_bf16);
