@@ -419,28 +419,77 @@ __device__ __forceinline__ TrAddr tr_addresses(int lane, int wm, int wn) {
   return a;
 }
 
-// one 64-pixel step: acc[i][j] += G^T(tile i) . X(tile j)
+// LDS byte address of a pointer into the dynamic-LDS region
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)p;
+}
+
+// Transposing LDS read as inline asm, NOT the builtin: behind a `global_load_lds` the compiler's wait-count pass puts an
+// `s_waitcnt vmcnt(0)` in front of every `llvm.amdgcn.ds.read.tr16.b64` (it cannot tell the read from the DMA's destination),
+// which drains the prefetched stages before the first read of each step -- DMA and MFMAs then never overlap inside a
+// workgroup (round 2's kernels ran that way: 30 % MFMA-busy at any tile size or ring depth).  With asm reads the order is
+// ours to keep: counted vmcnt + raw s_barrier before the reads, lgkmcnt(0) (tied to the destination registers, so that the
+// MFMAs cannot be scheduled above it) before their use.
+template <int OFF>
+__device__ __forceinline__ short4_t lds_read_tr(unsigned addr) {
+  short4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ void lds_wait_all(short4_t (&a)[2][2][2], short4_t (&b)[2][2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0][0][0]), "+v"(a[0][0][1]), "+v"(a[0][1][0]), "+v"(a[0][1][1]), "+v"(a[1][0][0]), "+v"(a[1][0][1]),
+                 "+v"(a[1][1][0]), "+v"(a[1][1][1]), "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]),
+                 "+v"(b[1][0][0]), "+v"(b[1][0][1]), "+v"(b[1][1][0]), "+v"(b[1][1][1])
+               :
+               : "memory");
+}
+
+// one 64-pixel step: acc[i][j] += G^T(tile i) . X(tile j).  Reads of k-steps 2-3 are in flight under the MFMAs of k-steps 0-1.
 __device__ __forceinline__ void tr_compute_step(const unsigned char *pG, const unsigned char *pX, const TrAddr &ad, f32x16 (&acc)[2][2]) {
   typedef __attribute__((ext_vector_type(8))) short short8_t;
+  const unsigned aG = lds_addr(pG), aX = lds_addr(pX);
+  short4_t g0[2][2][2], x0[2][2][2], g1[2][2][2], x1[2][2][2];  // [k-step of the pair][tile j][half]
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    bf16x8 a[2], b[2];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + ad.g[j][0]));
-      short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pG + ks * 16 * 256 + ad.g[j][1]));
-      short4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + ad.x[j][0]));
-      short4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3))) *)(pX + ks * 16 * 256 + ad.x[j][1]));
-      short8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      short8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      a[j] = __builtin_bit_cast(bf16x8, av);
-      b[j] = __builtin_bit_cast(bf16x8, bv);
+    for (int h = 0; h < 2; ++h) {
+      g0[0][j][h] = lds_read_tr<0>(aG + ad.g[j][h]);
+      x0[0][j][h] = lds_read_tr<0>(aX + ad.x[j][h]);
+      g0[1][j][h] = lds_read_tr<16 * 256>(aG + ad.g[j][h]);
+      x0[1][j][h] = lds_read_tr<16 * 256>(aX + ad.x[j][h]);
     }
+  lds_wait_all(g0, x0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-  }
+    for (int h = 0; h < 2; ++h) {
+      g1[0][j][h] = lds_read_tr<32 * 256>(aG + ad.g[j][h]);
+      x1[0][j][h] = lds_read_tr<32 * 256>(aX + ad.x[j][h]);
+      g1[1][j][h] = lds_read_tr<48 * 256>(aG + ad.g[j][h]);
+      x1[1][j][h] = lds_read_tr<48 * 256>(aX + ad.x[j][h]);
+    }
+  auto mfma_pair = [&](short4_t (&g)[2][2][2], short4_t (&x)[2][2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        short8_t av = {g[ks][j][0][0], g[ks][j][0][1], g[ks][j][0][2], g[ks][j][0][3], g[ks][j][1][0], g[ks][j][1][1], g[ks][j][1][2], g[ks][j][1][3]};
+        short8_t bv = {x[ks][j][0][0], x[ks][j][0][1], x[ks][j][0][2], x[ks][j][0][3], x[ks][j][1][0], x[ks][j][1][1], x[ks][j][1][2], x[ks][j][1][3]};
+        a[j] = __builtin_bit_cast(bf16x8, av);
+        b[j] = __builtin_bit_cast(bf16x8, bv);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  mfma_pair(g0, x0);
+  lds_wait_all(g1, x1);
+  mfma_pair(g1, x1);
 }
 
 // partial slab [Cout][Ktot] (fp32) of one split: rows = co, lanes = k columns (contiguous)
@@ -553,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
   for (int t = 0; t < nsteps; ++t) {
     const int buf = t & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();  // raw: __syncthreads() would add its own vmcnt(0) lgkmcnt(0) (harmless here, not in the ring below)
     if (t + 1 < nsteps) { advance(); stage(buf ^ 1); }
     const unsigned char *pG = sG + buf * T_BYTES, *pX = sX + buf * T_BYTES;
     tr_compute_step(pG, pX, ad, acc);
@@ -688,7 +737,7 @@ __global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const
     // stage t has landed when at most the younger stages' pieces are outstanding
     if (STAGES == 3 && t + 1 < nsteps) wait_vmcnt<PER_STAGE>();
     else wait_vmcnt<0>();
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() drains vmcnt to 0 and with it the stage just prefetched
     if (t + STAGES - 1 < nsteps) { advance(); stage((t + STAGES - 1) % STAGES); }
     const unsigned char *pS = smem + buf * SB;
     tr_compute_step(pS + offG, pS + offX, ad, acc);
@@ -777,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_tr_kernel(const bf16_t *_
   for (int t = 0; t < nsteps; ++t) {
     const int buf = t & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step t in LDS, step t + 1's pair indices in registers
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
     if (t + 1 < nsteps) { stage(buf ^ 1); advance(); }
     tr_compute_step(sG + buf * T_BYTES, sX + buf * T_BYTES, ad, acc);
   }
