@@ -632,7 +632,7 @@ __global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned *taps = (unsigned *)(smem + STAGES * SB);
   const ConvGeom &g = wg.c;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index in an SGPR
   const int tiles = wg.tiles_co * wg.tiles_k;
   const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles * wg.splits);
   const int split = (int)(lb / tiles), tile = (int)(lb - (long long)split * tiles);
@@ -645,27 +645,40 @@ __global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const
   if (p_end > g.M) p_end = g.M;
   const int nsteps = p_end > p_begin ? (int)((p_end - p_begin + BP - 1) / BP) : 0;
 
-  // staging: one DMA instruction = 4 rows x 256 B of one panel; wave w stages row groups [GPW * w, GPW * (w + 1)) of EVERY panel
+  // staging: one DMA instruction = 4 rows x 256 B of one panel; wave w stages row groups [GPW * w, GPW * (w + 1)) of EVERY panel.
+  // Address generation is incremental and 32-bit (the host checks that both tensors have < 2^31 elements and OH * OW >= 64):
+  // a piece's source is x + xb[row group] + xoff[slot] with xb = ((n*H + oh*stride - pad)*W + ow*stride - pad)*ldx moved by a
+  // constant per step plus one correction per row / image wrap, and xoff = (dh*W + dw)*ldx + ci fixed for the whole kernel --
+  // no multiply and no division inside the loop (round 2's form spent ~150 vector instructions per wave and step here, several
+  // of them quarter-rate 64-bit multiplies, beside 16 MFMAs).
   const int lrow = lane >> 4, lpos = lane & 15;
-  int pn[GPW], poh[GPW], pow_[GPW];
-  long long pm[GPW];
+  int rem[GPW], hb[GPW], wb[GPW], xb[GPW], gb[GPW];
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
-    long long m = p_begin + (GPW * w + i) * 4 + lrow;
-    pm[i] = m;
-    long long mm = m < g.M ? m : 0;
-    int n = (int)(mm / ((long long)g.OH * g.OW));
-    int rem = (int)(mm - (long long)n * g.OH * g.OW);
-    pn[i] = n;
-    poh[i] = rem / g.OW;
-    pow_[i] = rem - poh[i] * g.OW;
+    const long long m = p_begin + (GPW * w + i) * 4 + lrow;
+    rem[i] = (int)(p_end - m);
+    const long long mm = m < g.M ? m : 0;
+    const int n = (int)(mm / ((long long)g.OH * g.OW));
+    const int r2 = (int)(mm - (long long)n * g.OH * g.OW);
+    const int oh = r2 / g.OW, ow = r2 - oh * g.OW;
+    hb[i] = oh * g.stride - g.pad;
+    wb[i] = ow * g.stride - g.pad;
+    xb[i] = ((n * g.H + hb[i]) * g.W + wb[i]) * g.ldx;
+    gb[i] = (int)mm * wg.ldg;
   }
-  __syncthreads();
+  const int q64 = BP / g.OW, r64 = BP - q64 * g.OW;
+  const int adv_h = q64 * g.stride, adv_w = r64 * g.stride;
+  const int adv_x = (adv_h * g.W + adv_w) * g.ldx;
+  const int wlim = g.OW * g.stride - g.pad, hlim = g.OH * g.stride - g.pad;
+  const int wrap_w = g.OW * g.stride, wrap_h = g.OH * g.stride;
+  const int fix_w = (g.stride * g.W - wrap_w) * g.ldx;        // ow: OW -> 0, oh + 1
+  const int fix_h = (g.H * g.W - wrap_h * g.W) * g.ldx;       // oh: OH -> 0, n + 1
+  const int adv_g = BP * wg.ldg;
+  __syncthreads();  // tap table ready
 
   // a lane's pieces are fixed for the whole kernel: dy channel block of G panel p / K piece (tap, ci) of X panel p, row group i
-  unsigned xinfo[GPW][PX];
+  int xoff[GPW][PX], xdh[GPW][PX], xdw[GPW][PX], gco[GPW][PG];
   bool qok[GPW][PX], cok[GPW][PG];
-  int gco[GPW][PG];
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
     const int r = (GPW * w + i) * 4 + lrow;
@@ -679,7 +692,10 @@ __global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const
     for (int p = 0; p < PX; ++p) {
       const int q = q0 + p * 16 + c;
       qok[i][p] = q < g.nq;
-      xinfo[i][p] = qok[i][p] ? taps[q] : 0u;
+      const unsigned info = qok[i][p] ? taps[q] : 0u;
+      xdh[i][p] = (int)(info >> 24);
+      xdw[i][p] = (int)((info >> 16) & 0xff);
+      xoff[i][p] = (xdh[i][p] * g.W + xdw[i][p]) * g.ldx + (int)(info & 0xffff);
     }
   }
   const bf16_t *zsrc = zero_src();
@@ -687,29 +703,30 @@ __global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const
     unsigned char *base = smem + buf * SB;
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
-      const bool rok = pm[i] < p_end;
+      const bool rok = rem[i] > 0;
       const int rowoff = ((GPW * w + i) * 4) * 256;
-      const bf16_t *grow = dy + (size_t)pm[i] * wg.ldg;
 #pragma unroll
-      for (int p = 0; p < PG; ++p) glds16((rok && cok[i][p]) ? grow + gco[i][p] : zsrc, base + p * PANEL + rowoff);
-      const int hb = poh[i] * g.stride - g.pad, wb = pow_[i] * g.stride - g.pad;
+      for (int p = 0; p < PG; ++p)
+        glds16((rok && cok[i][p]) ? dy + (unsigned)(gb[i] + gco[i][p]) : zsrc, base + p * PANEL + rowoff);
 #pragma unroll
       for (int p = 0; p < PX; ++p) {
-        const unsigned info = xinfo[i][p];
-        const int ih = hb + (int)(info >> 24), iw = wb + (int)((info >> 16) & 0xff);
-        const bool ok = rok && qok[i][p] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-        const bf16_t *sx = ok ? x + ((size_t)((pn[i] * g.H + ih) * g.W + iw) * g.ldx + (info & 0xffff)) : zsrc;
-        glds16(sx, base + (PG + p) * PANEL + rowoff);
+        const bool ok = rok && qok[i][p] && (unsigned)(hb[i] + xdh[i][p]) < (unsigned)g.H &&
+                        (unsigned)(wb[i] + xdw[i][p]) < (unsigned)g.W;
+        glds16(ok ? x + (unsigned)(xb[i] + xoff[i][p]) : zsrc, base + (PG + p) * PANEL + rowoff);
       }
     }
   };
   auto advance = [&]() {
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
-      pm[i] += BP;
-      pow_[i] += BP;
-      while (pow_[i] >= g.OW) { pow_[i] -= g.OW; ++poh[i]; }
-      while (poh[i] >= g.OH) { poh[i] -= g.OH; ++pn[i]; }
+      rem[i] -= BP;
+      gb[i] += adv_g;
+      int dx = adv_x;
+      wb[i] += adv_w;
+      hb[i] += adv_h;
+      if (wb[i] >= wlim) { wb[i] -= wrap_w; hb[i] += g.stride; dx += fix_w; }
+      if (hb[i] >= hlim) { hb[i] -= wrap_h; dx += fix_h; }
+      xb[i] += dx;
     }
   };
 
@@ -1124,9 +1141,10 @@ static void wgrad_plan(long long M, int Cout, int Ktot, int *splits, long long *
 // Tile shape of the weight gradient: 0 = 128 x 128 (conv_wgrad_kernel, two workgroups per CU), 1 = 128 co x 256 k and
 // 2 = 256 co x 128 k (conv_wgrad_wide_kernel, three stages, one 512-thread workgroup per CU).  The wide tiles need K (resp.
 // Cout) beyond one 128-column panel, a tap table that fits beside three 48 KB stages, and enough pixels for >= 6 steps.
-static int wgrad_shape(long long M, int Cout, int Ktot) {
+static int wgrad_shape(long long M, int Cout, int Ktot, long long ohow) {
   static const int wide = [] { const char *e = getenv("BFHIP_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
-  if (!wide || Ktot / 8 > 3584 || M < 64 * 6) return 0;
+  // ohow >= 64: the wide kernel's incremental addressing assumes at most one row wrap and one image wrap per 64-pixel step
+  if (!wide || Ktot / 8 > 3584 || M < 64 * 6 || ohow < 64) return 0;
   if (Ktot > 128) return 1;
   if (Cout > 128) return 2;
   return 0;
@@ -1140,15 +1158,17 @@ static void wgrad_plan_wide(long long M, int Cout, int Ktot, int shape, int *spl
   long long steps = (M + 63) / 64;
   const int slots = resident_blocks() / 2;          // one workgroup per CU (3 x 48 KB of LDS), one residency round
   int want = tiles >= slots ? 1 : slots / tiles;
-  if (want > steps / 6) want = (int)(steps / 6);    // at least 6 steps per workgroup (the ring is 3 deep)
+  static const int min_steps = [] { const char *e = getenv("BFHIP_WGRAD_MIN_STEPS"); return e && atoi(e) > 0 ? atoi(e) : 6; }();
+  if (want > steps / min_steps) want = (int)(steps / min_steps);  // at least 6 steps per workgroup (the ring is 3 deep)
   if (want < 1) want = 1;
   long long per = (steps + want - 1) / want;
   *splits = (int)((steps + per - 1) / per);
   *rows_per_split = per * 64;
 }
 
-static void wgrad_plan_any(long long M, int Cout, int Ktot, int *shape, int *splits, long long *rps, int *tco, int *tk) {
-  *shape = wgrad_shape(M, Cout, Ktot);
+static void wgrad_plan_any(long long M, long long ohow, int Cout, int Ktot, int *shape, int *splits, long long *rps, int *tco,
+                           int *tk) {
+  *shape = wgrad_shape(M, Cout, Ktot, ohow);
   if (*shape) wgrad_plan_wide(M, Cout, Ktot, *shape, splits, rps, tco, tk);
   else wgrad_plan(M, Cout, Ktot, splits, rps, tco, tk);
 }
@@ -1156,7 +1176,7 @@ static void wgrad_plan_any(long long M, int Cout, int Ktot, int *shape, int *spl
 BFHIP_EXPORT size_t bfhip_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
   int shape, splits, tco, tk;
   long long rps;
-  wgrad_plan_any((long long)N * OH * OW, Cout, KH * KW * Cin, &shape, &splits, &rps, &tco, &tk);
+  wgrad_plan_any((long long)N * OH * OW, (long long)OH * OW, Cout, KH * KW * Cin, &shape, &splits, &rps, &tco, &tk);
   return align_up((size_t)splits * Cout * KH * KW * Cin * sizeof(float), 256);
 }
 
@@ -1180,7 +1200,9 @@ BFHIP_EXPORT int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int 
   g.Kout = Cout; g.ldw = 0; g.ldy = 0;
   wg.Cout = Cout; wg.ldg = ldg;
   int shape;
-  wgrad_plan_any(g.M, Cout, KH * KW * Cin, &shape, &wg.splits, &wg.rows_per_split, &wg.tiles_co, &wg.tiles_k);
+  BFHIP_REQUIRE((long long)N * H * W * ldx < (1LL << 31) && g.M * ldg < (1LL << 31),
+                "conv2d_wgrad: tensors of 2^31 elements or more are not supported");
+  wgrad_plan_any(g.M, (long long)g.OH * g.OW, Cout, KH * KW * Cin, &shape, &wg.splits, &wg.rows_per_split, &wg.tiles_co, &wg.tiles_k);
   BFHIP_REQUIRE(workspace_bytes >= bfhip_conv2d_wgrad_workspace_bytes(N, g.OH, g.OW, Cin, Cout, KH, KW), "conv2d_wgrad: workspace too small");
   static bool attr_set = false;
   if (!attr_set) {
