@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Does the bench line reproduce from the kernel trace of the same run?
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d D -o full -- python3 bench.py --steps K --warmup W --no-cpu-baseline > line.json
+    python3 tools/check_roofline_vs_trace.py line.json D/.../full_kernel_trace.csv > profiles/rNN_roofline_vs_trace.txt
+
+For every entry of `roofline_ops` the per-step time bench.py printed (HIP events of the library around the op: `kernel_ms_per_step`
+from the one-queue pass for the ops of the LiDAR branch, `ms_per_step` of the timed region for the rest) is set beside the same
+op's kernels in the trace: sum of kernel durations / number of steps, taken over the part of the trace the bench figure was
+measured in (the one-queue pass = the optimizer steps after the timed region; the timed region = the K steps before it).
+An event pair brackets the whole op, so it also sees the launch gaps between the op's kernels: `gap` columns show how much.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+# bench op -> regexes of its kernels
+FAMILIES = {
+    "hard_voxelize": [r"vox_", r"voxel_"],
+    "spconv_fwd+spconv_bwd": [r"spconv_gemm", r"spconv_scalar_kernel", r"pack_weights"],
+    "spconv_wgrad_main": [r"spconv_wgrad"],
+    "rulebook": [r"fill_pair_kernel", r"subm_insert_kernel", r"subm_pairs", r"sparse_mark_kernel", r"words_count_kernel",
+                 r"blocks_scan_kernel", r"words_prefix_kernel", r"sparse_out_indices_kernel", r"sparse_pairs", r"row_mask_kernel",
+                 r"merge_sort|block_sort|wrapped_merge"],
+    "lift_splat_fwd": [r"lift_splat_fwd"],
+    "lift_splat_bwd": [r"lift_splat_bwd"],
+    "conv2d_fwd": [r"conv_igemm_kernel<[^>]*, 0>"],
+    "conv2d_dgrad": [r"conv_igemm_kernel<[^>]*, [12]>", r"conv_weight_transpose"],
+    "conv2d_wgrad": [r"conv_wgrad_kernel", r"conv_wgrad_wide_kernel", r"conv_wgrad_reduce_kernel"],
+    "bn2d_fwd": [r"bn2d_stats", r"bn2d_finalize_kernel<[^>]*FwdFin", r"bn2d_apply"],
+    "bn2d_bwd": [r"bn2d_bwd", r"bn2d_finalize_kernel<[^>]*BwdFin"],
+}
+LIDAR = ("hard_voxelize", "spconv_fwd+spconv_bwd", "spconv_wgrad_main", "rulebook")
+
+
+def main(line_path, trace_path):
+    line = json.loads(open(line_path).read().strip().splitlines()[-1])
+    rows = list(csv.DictReader(open(trace_path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    names = [r["Kernel_Name"] for r in rows]
+    # optimizer steps = clusters of the fused AdamW launches
+    adam = [i for i, n in enumerate(names) if "FusedOptimizer" in n or ("multi_tensor_apply" in n and "Adam" in n)]
+    ends = []
+    for i in adam:
+        if ends and i - ends[-1] < 50:
+            ends[-1] = i
+        else:
+            ends.append(i)
+    K, W = line["steps"], line["warmup"]
+    iso = len(ends) - K - W
+    print("trace: %d kernels, %d optimizer steps = %d warm-up + %d timed + %d one-queue steps after the timed region" % (len(rows), len(ends), W, K, iso))
+    assert iso >= 0, "fewer optimizer steps in the trace than the bench line claims"
+    timed = (ends[W - 1] + 1 if W else 0, ends[W + K - 1] + 1)
+    after = (ends[W + K - 1] + 1, ends[-1] + 1) if iso else None
+    ops = {r["kernel"]: r for r in line["roofline_ops"]}
+    bench = {}
+    for op, r in ops.items():
+        bench[op] = (r.get("kernel_ms_per_step", r["ms_per_step"]), "one-queue pass" if "kernel_ms_per_step" in r else "timed region")
+    if "spconv_fwd" in bench and "spconv_bwd" in bench:
+        bench["spconv_fwd+spconv_bwd"] = (bench["spconv_fwd"][0] + bench["spconv_bwd"][0], bench["spconv_fwd"][1])
+    # the slab-sum kernel serves the sparse weight gradient too (20 of its launches per step): it is booked under conv2d_wgrad
+    # here and under spconv_wgrad in bench.py; spconv_wgrad_main (main kernel only) is the comparable sparse figure
+    print("%-24s %-15s %10s %10s %7s %9s   %s" % ("op", "bench figure", "bench ms", "trace ms", "ratio", "launches", "kernels"))
+    worst = 0.0
+    for op, pats in FAMILIES.items():
+        if op not in bench:
+            continue
+        b, where = bench[op]
+        lo, hi = (after if (where == "one-queue pass" and after) else timed)
+        n_steps = iso if (where == "one-queue pass" and after) else K
+        tot, cnt = 0, 0
+        kn = collections.Counter()
+        for r in rows[lo:hi]:
+            if any(re.search(p, r["Kernel_Name"]) for p in pats):
+                tot += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                cnt += 1
+                kn[re.sub(r".*::", "", r["Kernel_Name"].split("(")[0])[:28]] += 1
+        t = tot / 1e6 / n_steps
+        if op == "conv2d_wgrad" and "spconv_wgrad_main" in bench:  # remove the sparse layers' share of the shared slab-sum kernel
+            red = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[lo:hi] if "conv_wgrad_reduce_kernel" in r["Kernel_Name"]]
+            per = len(red) / n_steps
+            if per > 77:
+                t -= sum(red) / 1e6 / n_steps * (per - 77) / per
+        ratio = b / t if t else float("nan")
+        worst = max(worst, abs(ratio - 1.0)) if t else worst
+        print("%-24s %-15s %10.4f %10.4f %7.2f %9.1f   %s" % (op, where, b, t, ratio, cnt / n_steps, ", ".join("%s x%d" % (k, v // n_steps) for k, v in kn.most_common(4))))
+    print("largest deviation of a bench figure from its kernels in the trace: %.1f %%" % (100 * worst))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
