@@ -16,7 +16,8 @@ if [ "$part" = A ]; then
   BENCH_GRAPH=1 run timeout -k 10 200 python3 bench.py --no-cpu-baseline > $O/bench_full_graph.json 2> $O/bench_graph.err || exit 1
   BFHIP_SPCONV_SORT=0 run timeout -k 10 200 python3 bench.py --no-cpu-baseline > $O/bench_full_nosort.json 2> $O/bench_nosort.err || exit 1
 elif [ "$part" = B ]; then
-  run timeout -k 10 300 BENCH_REFERENCE_NUMERICS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_full -o full -- python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/bench_full_under_rocprof.json 2> $O/prof_full.err || exit 1
+  export BENCH_REFERENCE_NUMERICS=0
+  run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_full -o full -- python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/bench_full_under_rocprof.json 2> $O/prof_full.err || exit 1
   T=$(find $O/prof_full -name 'full_kernel_trace.csv' | head -1); S=$(find $O/prof_full -name 'full_kernel_stats.csv' | head -1)
   cp $S $O/bench_full_kernel_stats.csv
   python3 tools/trace_step.py $T > $O/bench_full_last_step_breakdown.txt
