@@ -88,3 +88,20 @@ def test_cpu_tensors_are_rejected():
     vox = Voxelization([1.0, 1.0, 1.0], [0, 0, 0, 4, 4, 4], 5, 20)
     with pytest.raises(RuntimeError):
         vox(torch.zeros(10, 4))
+
+
+def test_conv2d_supported_rejects_what_the_kernels_cannot_hold():
+    """bfhip_conv2d_supported is what routes a layer to the HIP kernels or to the library (conv2d.Conv2d.hip_eligible): it must say
+    no to geometries whose tap tables do not fit beside the LDS stages -- for Cin (forward, weight gradient) AND Cout (the data
+    gradient gathers over Cout) -- so that such layers fall back to torch instead of failing at launch.  Host-only call."""
+    from bevfusion_amd import _lib
+    lib = _lib.load()
+    ok = lambda *a: lib.bfhip_conv2d_supported(*a)  # noqa: E731  (N, H, W, Cin, Cout, KH, KW, stride, pad, dil)
+    assert ok(4, 180, 180, 336, 256, 3, 3, 1, 1, 1) == 1            # ConvFuser
+    assert ok(24, 8, 22, 512, 512, 3, 3, 1, 1, 1) == 1              # widest 3x3 of ResNet-50: 576 pieces
+    assert ok(24, 16, 44, 3072, 256, 1, 1, 1, 0, 1) == 1            # LSS-FPN lateral 1x1
+    assert ok(1, 32, 32, 4096, 64, 3, 3, 1, 1, 1) == 0              # 4608 pieces along Cin
+    assert ok(1, 32, 32, 64, 4096, 3, 3, 1, 1, 1) == 0              # 4608 pieces along Cout (data gradient)
+    assert ok(1, 32, 32, 64, 65536, 1, 1, 1, 0, 1) == 0             # 16-bit channel field of the tap table
+    assert ok(1, 32, 32, 60, 64, 3, 3, 1, 1, 1) == 0                # channels not a multiple of 8
+    assert ok(1, 32, 32, 64, 64, 3, 3, 3, 1, 1) == 0                # stride not a power of two

@@ -62,8 +62,12 @@ def main(line_path, trace_path):
         bench["spconv_fwd+spconv_bwd"] = (bench["spconv_fwd"][0] + bench["spconv_bwd"][0], bench["spconv_fwd"][1])
     # the slab-sum kernel serves the sparse weight gradient too (20 of its launches per step): it is booked under conv2d_wgrad
     # here and under spconv_wgrad in bench.py; spconv_wgrad_main (main kernel only) is the comparable sparse figure
-    print("%-24s %-15s %10s %10s %7s %9s   %s" % ("op", "bench figure", "bench ms", "trace ms", "ratio", "launches", "kernels"))
+    print("columns: bench ms = HIP-event scope per step as printed by bench.py; kernels ms = sum of the op's kernel durations per step;\n"
+          "span ms = per op instance, first kernel start -> last kernel end (what an event pair brackets: kernel time + the dispatch gaps\n"
+          "between the op's own kernels, which tracing itself widens), summed per step; ratio = bench / span")
+    print("%-24s %-15s %10s %10s %10s %7s %9s   %s" % ("op", "bench figure", "bench ms", "kernels ms", "span ms", "ratio", "launches", "kernels"))
     worst = 0.0
+    neutral = re.compile(r"__amd_rocclr_(fill|copy)Buffer")
     for op, pats in FAMILIES.items():
         if op not in bench:
             continue
@@ -78,15 +82,35 @@ def main(line_path, trace_path):
                 cnt += 1
                 kn[re.sub(r".*::", "", r["Kernel_Name"].split("(")[0])[:28]] += 1
         t = tot / 1e6 / n_steps
+        # spans: per queue, maximal runs of the op's kernels (runtime memset / copy kernels in between do not break a run)
+        span = 0
+        by_q = collections.defaultdict(list)
+        for r in rows[lo:hi]:
+            by_q[r.get("Queue_Id", "0")].append(r)
+        for q_rows in by_q.values():
+            first = last = None
+            for r in q_rows:
+                fam = any(re.search(p, r["Kernel_Name"]) for p in pats)
+                if fam:
+                    first = first if first is not None else int(r["Start_Timestamp"])
+                    last = int(r["End_Timestamp"])
+                elif not neutral.search(r["Kernel_Name"]) and first is not None:
+                    span += last - first
+                    first = last = None
+            if first is not None:
+                span += last - first
+        sp = span / 1e6 / n_steps
         if op == "conv2d_wgrad" and "spconv_wgrad_main" in bench:  # remove the sparse layers' share of the shared slab-sum kernel
             red = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[lo:hi] if "conv_wgrad_reduce_kernel" in r["Kernel_Name"]]
             per = len(red) / n_steps
             if per > 77:
-                t -= sum(red) / 1e6 / n_steps * (per - 77) / per
-        ratio = b / t if t else float("nan")
-        worst = max(worst, abs(ratio - 1.0)) if t else worst
-        print("%-24s %-15s %10.4f %10.4f %7.2f %9.1f   %s" % (op, where, b, t, ratio, cnt / n_steps, ", ".join("%s x%d" % (k, v // n_steps) for k, v in kn.most_common(4))))
-    print("largest deviation of a bench figure from its kernels in the trace: %.1f %%" % (100 * worst))
+                cut = sum(red) / 1e6 / n_steps * (per - 77) / per
+                t -= cut
+                sp -= cut
+        ratio = b / sp if sp else float("nan")
+        worst = max(worst, abs(ratio - 1.0)) if sp else worst
+        print("%-24s %-15s %10.4f %10.4f %10.4f %7.2f %9.1f   %s" % (op, where, b, t, sp, ratio, cnt / n_steps, ", ".join("%s x%d" % (k, v // n_steps) for k, v in kn.most_common(4))))
+    print("largest deviation of a bench figure from its span in the trace: %.1f %%" % (100 * worst))
 
 
 if __name__ == "__main__":
