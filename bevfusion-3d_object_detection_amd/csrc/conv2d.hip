@@ -239,9 +239,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
   static_assert(NA >= 1 && NA * 8 * NWAVES == BM && NB >= 1 && NB * 8 * NWAVES == BN, "tiles must split into whole DMA instructions");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned *taps = (unsigned *)(smem + STAGES * S_BYTES);
-  // second table (round 3): piece q -> { element offset of the tap relative to the row's base pixel, (dh, dw) as signed 16-bit
-  // steps in the gathered tensor's coordinates }: the source of a piece is x + rowbase + offset, no multiply per piece
-  int2 *taps2 = (int2 *)(taps + ((g.nq + 1) & ~1));
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles_m * tiles_n);
   const int tn = (int)(lb % tiles_n);
@@ -263,26 +260,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
   for (int q = tid; q < nq; q += NTHREADS) {
     int k = q * 8;
     int tap = k / g.C, ci = k - tap * g.C;
-    int kh, kw, ah, aw;
+    int kh, kw;
     if (MODE == 2) {  // the class's taps only (dilation 1)
-      const int a = tap / pc.nkw, b = tap - a * pc.nkw;
+      const int a = tap / pc.nkw;
       kh = pc.kh0 + a * g.stride;
-      kw = pc.kw0 + b * g.stride;
-      ah = -a;   // rows are (h0 + i*stride): the tap reaches gathered pixel (base - a, base - b), see bh / bw below
-      aw = -b;
+      kw = pc.kw0 + (tap - a * pc.nkw) * g.stride;
     } else {
       kh = tap / g.KW;
       kw = tap - kh * g.KW;
-      ah = TR ? -kh * g.dil : kh * g.dil;
-      aw = TR ? -kw * g.dil : kw * g.dil;
     }
     taps[q] = ((unsigned)(kh * g.dil) << 24) | ((unsigned)(kw * g.dil) << 16) | (unsigned)ci;
-    taps2[q] = make_int2((ah * g.W + aw) * g.ldx + ci, (int)(((unsigned)ah & 0xffffu) | ((unsigned)aw << 16)));
   }
 
   // ---- per-lane staging state: NA A rows (one per DMA instruction) and NB B rows; every wave stages NA*8 A rows
   const int lrow = lane >> 3, lpos = lane & 7;
-  int nb[NA], hb[NA], wb[NA], bh[NA], bw[NA], rowbase[NA];
+  int nb[NA], hb[NA], wb[NA];
   bool rok[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -306,13 +298,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
     nb[i] = n * g.H * g.W;
     hb[i] = TR ? oh + g.pad : oh * g.stride - g.pad;
     wb[i] = TR ? ow + g.pad : ow * g.stride - g.pad;
-    // linear form: base pixel of the row in the gathered tensor (MODE 2: (hb - kh0) is a multiple of the stride by construction)
-    bh[i] = MODE == 2 ? (hb[i] - pc.kh0) >> g.sshift : hb[i];
-    bw[i] = MODE == 2 ? (wb[i] - pc.kw0) >> g.sshift : wb[i];
-    rowbase[i] = (nb[i] + bh[i] * g.W + bw[i]) * g.ldx;
   }
-  // MODE 1 with a stride > 1 (parity classes switched off) keeps the general per-piece address computation
-  const bool linear = !(MODE == 1 && g.sshift != 0);
   const bf16_t *wrow[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -323,32 +309,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
 
   const int nt = (nq + 7) >> 3;
   const bf16_t *zsrc = zero_src();
-  // table entries of the NEXT stage to issue, fetched one step ahead of their use (the LDS latency of the tap lookup was
-  // exposed NA times per step in front of every stage's DMA issue)
-  int2 ent[NA];
-  auto load_ent = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int swz = ((w * (NA * 8) + i * 8 + lrow) >> 1) & 7;
-      const int q = t * 8 + (lpos ^ swz);
-      ent[i] = q < nq ? taps2[q] : make_int2(0, 0x8000);  // dh = -32768: fails the bounds test -> zero piece
-    }
-  };
   auto stage = [&](int t, int buf) {  // exactly GL DMA instructions per wave (the counted waits rely on it)
     unsigned char *dA = smem + buf * S_BYTES + (w * (NA * 8)) * 128;
     unsigned char *dB = smem + buf * S_BYTES + A_BYTES + (w * (NB * 8)) * 128;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const bf16_t *src;
-      if (linear) {
-        const int ih = bh[i] + (int)(short)(ent[i].y & 0xffff), iw = bw[i] + (ent[i].y >> 16);
-        const bool ok = rok[i] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-        src = ok ? x + (unsigned)(rowbase[i] + ent[i].x) : zsrc;
-      } else {
-        const int swz = ((w * (NA * 8) + i * 8 + lrow) >> 1) & 7;
-        const int q = t * 8 + (lpos ^ swz);
-        src = q < nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q], zsrc) : zsrc;
-      }
+      const int swz = ((w * (NA * 8) + i * 8 + lrow) >> 1) & 7;
+      const int q = t * 8 + (lpos ^ swz);
+      const bf16_t *src = q < nq ? piece_src<TR>(x, g, rok[i], nb[i], hb[i], wb[i], taps[q], zsrc) : zsrc;
       glds16(src, dA + i * 1024);
     }
 #pragma unroll
@@ -382,8 +350,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
 
 #pragma unroll
   for (int s0 = 0; s0 < STAGES - 1; ++s0)
-    if (s0 < nt) { load_ent(s0); stage(s0, s0); }
-  load_ent(STAGES - 1);
+    if (s0 < nt) stage(s0, s0);
   int buf = 0, nbuf = STAGES - 1;  // stage holding step t / stage the next DMA goes to
   for (int t = 0; t < nt; ++t) {
     // step t must have landed; the DMA of the (up to STAGES - 2) later steps stays in flight
@@ -392,10 +359,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
     else wait_vmcnt<2 * GL>();
     __builtin_amdgcn_s_barrier();  // all of step t is in LDS; every wave is done reading step t - 1
     const unsigned char *pA = smem + buf * S_BYTES + aoff, *pB = smem + buf * S_BYTES + boff;
-    if (t + STAGES - 1 < nt) {  // before the MFMAs: issuing it after the first K quarter's MFMAs (address generation in
-      stage(t + STAGES - 1, nbuf);  // their shadow) measured 5-10 % slower
-      load_ent(t + STAGES);         // next step's tap entries: in flight under this step's MFMAs
-    }
+    if (t + STAGES - 1 < nt) stage(t + STAGES - 1, nbuf);  // before the MFMAs: issuing it after the first K quarter's MFMAs
+                                                           // (address generation in their shadow) measured 5-10 % slower
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int pos = ((2 * ks + lh) ^ rswz) << 4;
@@ -939,21 +904,19 @@ __global__ __launch_bounds__(256) void conv_weight_transpose_kernel(const bf16_t
   }
 }
 
-// K pieces (16-byte = 8-channel pieces of one tap) a kernel can hold tables for: the two tap tables of the implicit GEMM
-// (12 bytes per piece) sit beside 64 KB of stages under the 80 KB dynamic-LDS attribute of the two-workgroups-per-CU tiles
-// (the 256-wide tiles have 31 KB beside 128 KB).  C is Cin for forward / weight gradient and Cout for the data gradient,
-// so bfhip_conv2d_supported checks both (round 2 checked Cin only and allowed 8192 pieces: such calls passed `supported`
-// and then failed at launch instead of falling back to the library).
-constexpr int kMaxPieces = 1280;
+// K pieces (16-byte = 8-channel pieces of one tap) a kernel can hold a tap table for: 4 bytes per piece beside 64 KB of
+// stages under the 80 KB dynamic-LDS attribute of the two-workgroups-per-CU tiles (the 256-wide tiles have 31 KB beside
+// 128 KB, the wide weight-gradient tiles 16 KB beside 144 KB).  C is Cin for forward / weight gradient and Cout for the data
+// gradient, so bfhip_conv2d_supported checks both (round 2 checked Cin only and allowed 8192 pieces: such calls passed
+// `supported` and then failed at launch instead of falling back to the library).
+constexpr int kMaxPieces = 3584;
 bool geom_ok(int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil) {
   return N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C < 65536 && KH > 0 && KW > 0 && stride > 0 &&
          (stride & (stride - 1)) == 0 /* the data gradient shifts instead of dividing */ && pad >= 0 && dil > 0 &&
          (KH - 1) * dil < 256 && (KW - 1) * dil < 256 && (long long)KH * KW * C / 8 <= kMaxPieces;
 }
 
-size_t igemm_lds_bytes(int BM, int BN, int stages, int nq) {  // stages + the two tap tables (4 + 8 bytes per K piece)
-  return (size_t)stages * (BM + BN) * 128 + (size_t)((nq + 1) & ~1) * 4 + (size_t)nq * 8;
-}
+size_t igemm_lds_bytes(int BM, int BN, int stages, int nq) { return (size_t)stages * (BM + BN) * 128 + (size_t)nq * 4; }
 
 
 // ---- internal entry points for spconv.hip (declared in common.h)
