@@ -239,6 +239,9 @@ class _ModelWorkload:
             broadcast_parameters(self.model)
             self.grad_sync = FlatGradAllReduce(self.model.parameters())
         self.parse_losses = BEVFusion.parse_losses
+        from bevfusion_amd import conv2d as _c2
+        _c2.WGRAD_SIDE_STREAM = os.environ.get("BENCH_WGRAD_SIDE_STREAM", "1") == "1"
+        self._wgrad_join = _c2.wgrad_join if _c2.WGRAD_SIDE_STREAM else None
         self._params = [p for p in self.model.parameters() if p.requires_grad]
         # ground truth as a dataloader hands it over: per-frame host tensors (boxes [G, 9], labels [G]), G ~ U(15, 60)
         self.gts = [tuple(torch.from_numpy(a) for a in synthetic.gt_boxes(seed=3000 + seed_base + i)) for i in range(batch)]
@@ -262,6 +265,8 @@ class _ModelWorkload:
             losses = self.step_model(self.inputs, None, gts)
             loss, self.log_vars = self.parse_losses(losses)  # (loss, log_vars) as BF/bevfusion.py:88-121
         loss.backward()
+        if self._wgrad_join is not None:
+            self._wgrad_join()  # weight gradients launched on their own stream (conv2d.WGRAD_SIDE_STREAM): join before any use
         return loss
 
     def _update(self):

@@ -29,6 +29,63 @@ MIN_CIN = int(os.environ.get("BFHIP_CONV2D_MIN_CIN", "16"))
 HYBRID_HIP_DGRAD = os.environ.get("BFHIP_HYBRID_HIP_DGRAD", "0") == "1"  # Conv2dHipWgrad: data gradient on the HIP kernel too  # tiny maps: the library's small-problem kernels win
 _WS = {}
 
+# Weight gradients on their own HIP stream (opt-in, BFHIP_WGRAD_SIDE_STREAM=1; bench.py switches it on and joins after the
+# backward): dW of a layer is a leaf of the backward graph -- nothing downstream waits for it until the optimizer -- and its
+# kernel is matrix-core / LDS bound, while the chain it would otherwise sit in (BatchNorm backward -> data gradient -> BatchNorm
+# backward ...) is dominated by HBM-bound BatchNorm passes and small launches that leave most CUs idle.  The caller MUST call
+# `wgrad_join()` after `backward()` and before anything reads a weight gradient (optimizer, clipping, gradient exchange).
+WGRAD_SIDE_STREAM = os.environ.get("BFHIP_WGRAD_SIDE_STREAM", "0") == "1"
+_SIDE = {}
+_KEEP = []  # operands of in-flight side-stream launches (kept alive until the join instead of record_stream per tensor)
+
+
+def _wgrad_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def wgrad_join():
+    """Make the current stream wait for every weight gradient launched on the side stream; release their operands."""
+    for dev, side in _SIDE.items():
+        torch.cuda.current_stream(dev).wait_stream(side)
+    _KEEP.clear()
+
+
+def _launch_wgrad(x, dy, weight, stride, pad, dil):
+    """dW [Cout, Cin, KH, KW] (channels-last memory) of a convolution; on the side stream when WGRAD_SIDE_STREAM is set."""
+    N, Cin, H, W = x.shape
+    Cout, _, KH, KW = weight.shape
+    OH, OW = dy.shape[2], dy.shape[3]
+    lib = _lib.load()
+    out_bf16 = weight.dtype == torch.bfloat16
+    side = None
+    if WGRAD_SIDE_STREAM:
+        main = torch.cuda.current_stream(x.device)
+        side = _wgrad_stream(x.device)
+        side.wait_stream(main)   # dy and x were produced by work already queued on the main stream
+        _KEEP.append((x, dy))
+    with torch.cuda.stream(side) if side is not None else _NullCtx():
+        stream = _lib.stream_of(x)
+        dw = torch.empty((Cout, KH, KW, Cin), dtype=weight.dtype if out_bf16 else torch.float32, device=x.device).permute(0, 3, 1, 2)
+        ws = _workspace(x.device, lib.bfhip_conv2d_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, KH, KW), stream)
+        _lib.call("bfhip_conv2d_wgrad", x.data_ptr(), _nhwc_view(x), dy.data_ptr(), _nhwc_view(dy), dw.data_ptr(), N, H, W, Cin,
+                  Cout, KH, KW, stride, pad, dil, 1 if out_bf16 else 0, ws.data_ptr(), ws.numel(), stream)
+        if dw.dtype != weight.dtype:
+            dw = dw.to(weight.dtype)
+        if side is not None:
+            _KEEP.append(dw)
+    return dw
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
 
 def _workspace(device, nbytes, stream):
     key = (device, stream)
@@ -111,14 +168,7 @@ class _Conv2dFunction(torch.autograd.Function):
             _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
                       W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
         if ctx.needs_input_grad[1]:
-            out_bf16 = weight.dtype == torch.bfloat16
-            dw = torch.empty((Cout, KH, KW, Cin), dtype=weight.dtype if out_bf16 else torch.float32,
-                             device=x.device).permute(0, 3, 1, 2)
-            ws = _workspace(x.device, lib.bfhip_conv2d_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, KH, KW), stream)
-            _lib.call("bfhip_conv2d_wgrad", x.data_ptr(), _nhwc_view(x), dy.data_ptr(), _nhwc_view(dy), dw.data_ptr(), N, H, W, Cin,
-                      Cout, KH, KW, stride, pad, dil, 1 if out_bf16 else 0, ws.data_ptr(), ws.numel(), stream)
-            if dw.dtype != weight.dtype:
-                dw = dw.to(weight.dtype)
+            dw = _launch_wgrad(x, dy, weight, stride, pad, dil)
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
         return dx, dw, db, None, None, None, None
@@ -154,16 +204,7 @@ class _LibConvHipWgradFunction(torch.autograd.Function):
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride] * 2, [pad] * 2, [dil] * 2, False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            stream = _lib.stream_of(x)
-            lib = _lib.load()
-            out_bf16 = weight.dtype == torch.bfloat16
-            dw = torch.empty((Cout, KH, KW, Cin), dtype=weight.dtype if out_bf16 else torch.float32,
-                             device=x.device).permute(0, 3, 1, 2)
-            ws = _workspace(x.device, lib.bfhip_conv2d_wgrad_workspace_bytes(N, OH, OW, Cin, Cout, KH, KW), stream)
-            _lib.call("bfhip_conv2d_wgrad", x.data_ptr(), _nhwc_view(x), dy.data_ptr(), _nhwc_view(dy), dw.data_ptr(), N, H, W, Cin,
-                      Cout, KH, KW, stride, pad, dil, 1 if out_bf16 else 0, ws.data_ptr(), ws.numel(), stream)
-            if dw.dtype != weight.dtype:
-                dw = dw.to(weight.dtype)
+            dw = _launch_wgrad(x, dy, weight, stride, pad, dil)
         return dx, dw, None, None, None
 
 

@@ -210,3 +210,34 @@ def test_conv_bn_relu_fused_statistics_match_unfused(dev):
         res.append((out.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.float(), conv.weight.grad.clone()))
     for a, b in zip(*res):
         assert _l2(a, b) < 3e-3, _l2(a, b)   # statistics from fp32 accumulators vs from the bf16-rounded tensor
+
+
+def test_weight_gradients_on_the_side_stream_are_identical(dev, monkeypatch):
+    """conv2d.WGRAD_SIDE_STREAM: the weight gradients of a stack of convolutions launched on their own HIP stream (joined by
+    wgrad_join() after the backward) equal, bit for bit, the ones launched in line -- same kernels, same operands; the
+    operands are kept alive until the join and the main stream does not read a dW before it."""
+    from bevfusion_amd import conv2d as c2
+    from bevfusion_amd.conv2d import Conv2d
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(Conv2d(32, 64, 3, padding=1, bias=False), Conv2d(64, 64, 3, stride=2, padding=1, bias=False),
+                              Conv2d(64, 128, 1, bias=False), Conv2d(128, 32, 3, padding=1, bias=False)).to(dev).train()
+    for m in net:
+        m.weight.data = m.weight.data.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(3, 32, 64, 88, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    grads = {}
+    for side in (False, True):
+        monkeypatch.setattr(c2, "WGRAD_SIDE_STREAM", side)
+        for p in net.parameters():
+            p.grad = None
+        for _ in range(3):  # several backward passes in flight behind each other: buffers are recycled while the side stream runs
+            y = net(x)
+            y.float().square().mean().backward()
+            # main-stream work that would overwrite freed operands if they were released too early
+            junk = [torch.randn(3, 64, 64, 88, device=dev) for _ in range(4)]
+            del junk
+        c2.wgrad_join()
+        torch.cuda.synchronize()
+        grads[side] = [p.grad.clone() for p in net.parameters()]
+    assert all(torch.isfinite(g.float()).all() and g.float().abs().sum() > 0 for g in grads[True])
+    for a, b in zip(grads[False], grads[True]):
+        assert torch.equal(a, b)
