@@ -61,7 +61,9 @@ def _launch_wgrad(x, dy, weight, stride, pad, dil):
     lib = _lib.load()
     out_bf16 = weight.dtype == torch.bfloat16
     side = None
-    if WGRAD_SIDE_STREAM:
+    # only when autograd will merely STORE the result (weight.grad is None: AccumulateGrad takes the tensor as it is, no
+    # kernel); a gradient that is accumulated into an existing .grad is read by an add on the main stream right away
+    if WGRAD_SIDE_STREAM and getattr(weight, "grad", None) is None:
         main = torch.cuda.current_stream(x.device)
         side = _wgrad_stream(x.device)
         side.wait_stream(main)   # dy and x were produced by work already queued on the main stream
@@ -74,8 +76,7 @@ def _launch_wgrad(x, dy, weight, stride, pad, dil):
                   Cout, KH, KW, stride, pad, dil, 1 if out_bf16 else 0, ws.data_ptr(), ws.numel(), stream)
         if dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)
-        if side is not None:
-            _KEEP.append(dw)
+    # (no reference to dw is kept here: AccumulateGrad only takes a gradient over without a copy when nobody else holds it)
     return dw
 
 

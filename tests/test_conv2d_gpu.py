@@ -227,17 +227,23 @@ def test_weight_gradients_on_the_side_stream_are_identical(dev, monkeypatch):
     grads = {}
     for side in (False, True):
         monkeypatch.setattr(c2, "WGRAD_SIDE_STREAM", side)
-        for p in net.parameters():
-            p.grad = None
-        for _ in range(3):  # several backward passes in flight behind each other: buffers are recycled while the side stream runs
-            y = net(x)
+        got = []
+        for it in range(3):  # several passes in flight behind each other: buffers are recycled while the side stream runs
+            for p in net.parameters():
+                p.grad = None
+            y = net(x * (1.0 + it))
             y.float().square().mean().backward()
             # main-stream work that would overwrite freed operands if they were released too early
             junk = [torch.randn(3, 64, 64, 88, device=dev) for _ in range(4)]
             del junk
+            c2.wgrad_join()
+            got.append([p.grad.clone() for p in net.parameters()])
+        # a second backward WITHOUT clearing .grad: autograd accumulates on the main stream, so these launches stay in line
+        net(x).float().square().mean().backward()
         c2.wgrad_join()
         torch.cuda.synchronize()
-        grads[side] = [p.grad.clone() for p in net.parameters()]
+        got.append([p.grad.clone() for p in net.parameters()])
+        grads[side] = [g for step in got for g in step]
     assert all(torch.isfinite(g.float()).all() and g.float().abs().sum() > 0 for g in grads[True])
     for a, b in zip(grads[False], grads[True]):
         assert torch.equal(a, b)
