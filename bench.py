@@ -51,9 +51,9 @@ GRAD_SYNC = os.environ.get("BENCH_GRAD_SYNC", "flat")
 PROFILE_LEVEL = int(os.environ.get("BENCH_PROFILE_LEVEL", "2"))
 DENSE_EVERY = max(1, int(os.environ.get("BENCH_PROFILE_DENSE_EVERY", "10")))
 DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd")
-# ops of the LiDAR branch: in `full` they run on a second HIP stream beside the camera branch, so an event pair around one of them
-# in the timed region also measures the wait for CUs the other queue holds.  Their roofline fraction is computed from
-# `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side stream off
+# `full` runs on three HIP queues (camera / BEV chain; LiDAR branch; weight gradients), so an event pair around an op in the
+# timed region also measures the wait for CUs the other queues hold.  Roofline fractions are computed from
+# `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side streams off
 # (one queue, nothing beside them) -- the number a rocprofv3 kernel trace reproduces.
 LIDAR_OPS = ("hard_voxelize", "spconv_fwd", "spconv_bwd", "spconv_wgrad", "spconv_wgrad_main", "rulebook")
 NO_WORK = os.environ.get("BENCH_NO_WORK") == "1"  # counter passes under rocprofv3: warm-up + timed steps only, nothing else
@@ -717,19 +717,22 @@ def main():
         _lib.profile_enable(False)
         prof = {op: _lib.profile_read(op, reset=True) for op in _lib.OPS}
         model = getattr(wl, "model", None)
-        if (ISOLATED_STEPS > 0 and not graphed and model is not None and getattr(model, "lidar_side_stream", False)
-                and getattr(wl, "lidar", False) and getattr(wl, "camera", False) and rank == 0):
-            # kernel-time pass for the LiDAR-branch ops (see LIDAR_OPS): same workload, one queue.  Outside the timed region.
-            model.lidar_side_stream = False
+        from bevfusion_amd import conv2d as _c2
+        overlapped = bool(model is not None and (getattr(model, "lidar_side_stream", False) or _c2.WGRAD_SIDE_STREAM))
+        if ISOLATED_STEPS > 0 and not graphed and overlapped and rank == 0:
+            # kernel-time pass: the same workload on ONE queue (LiDAR branch and weight gradients in line), every op timed.
+            # Outside the timed region.
+            side_lidar, side_wgrad = model.lidar_side_stream, _c2.WGRAD_SIDE_STREAM
+            model.lidar_side_stream, _c2.WGRAD_SIDE_STREAM = False, False
             torch.cuda.synchronize()
-            _lib.profile_enable(1)
+            _lib.profile_enable(PROFILE_LEVEL)
             for _ in range(ISOLATED_STEPS):
                 wl.step()
             torch.cuda.synchronize()
             _lib.profile_enable(False)
             iso = {op: _lib.profile_read(op, reset=True) for op in _lib.OPS}
             iso_steps = ISOLATED_STEPS
-            model.lidar_side_stream = True
+            model.lidar_side_stream, _c2.WGRAD_SIDE_STREAM = side_lidar, side_wgrad
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -744,8 +747,12 @@ def main():
                     "launches_per_step": cnt / (max(dense_steps, 1) if op in DENSE_OPS else prof_steps)}
                for op, (ms, cnt) in prof.items() if cnt}
         # dominant hand-written op of the step = the one with the largest accumulated event time
-        dom = max((op for op in work if prof.get(op, (0, 0))[1] and op != "spconv_wgrad_main"),
-                  key=lambda o: prof[o][0] / (max(dense_steps, 1) if o in DENSE_OPS else prof_steps), default=None)
+        def op_ms(o):  # one-queue kernel time where it was measured, else the event time of the timed region
+            if iso.get(o, (0, 0))[1]:
+                return iso[o][0] / iso_steps
+            return prof[o][0] / (max(dense_steps, 1) if o in DENSE_OPS else prof_steps)
+
+        dom = max((op for op in work if prof.get(op, (0, 0))[1] and op != "spconv_wgrad_main"), key=op_ms, default=None)
         # HBM traffic: PMC counters cannot be read from inside this process; the value is the rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE measurement committed under profiles/ (same batch-4 sizes), tagged with its source
         pmc, pmc_src = {}, None
@@ -772,12 +779,13 @@ def main():
             r = {"kernel": op, "bound": w["bound"], "ms_per_step": round(ms / n_steps, 5), "launches_per_step": cnt / n_steps,
                  "timed_steps_sampled": n_steps,
                  "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None}
-            if op in LIDAR_OPS and iso.get(op, (0, 0))[1]:
-                # second-stream op: `ms_per_step` above is the event time in the timed region (includes waiting for CUs the
-                # camera queue holds); every figure below is computed from the isolated kernel-time pass
-                r["event_ms_per_step_beside_camera_stream"] = r["ms_per_step"]
+            if iso.get(op, (0, 0))[1]:
+                # the step runs on three HIP queues (camera / BEV chain, LiDAR branch, weight gradients): `ms_per_step` above is
+                # the op's event time in the timed region and includes sharing the chip with the other queues; every figure
+                # below is computed from the one-queue pass, which a kernel trace reproduces
+                r["event_ms_per_step_in_timed_region"] = r["ms_per_step"]
                 r["kernel_ms_per_step"] = round(iso[op][0] / iso_steps, 5)
-                r["kernel_time_source"] = "%d steps after the timed region with lidar_side_stream=False (one queue)" % iso_steps
+                r["kernel_time_source"] = "%d steps after the timed region on one queue (no side streams)" % iso_steps
                 sec_per_step = iso[op][0] * 1e-3 / iso_steps
             if "scope" in w:
                 r["scope"] = w["scope"]
@@ -815,7 +823,11 @@ def main():
         }
         if hasattr(wl, "use_graph"):
             line["config"]["execution"] = ("whole step captured once into a hipGraph and replayed (per-op roofline times from %d eager "
-                                           "steps after the timed region)" % prof_steps) if graphed else "eager launches, two HIP streams"
+                                           "steps after the timed region)" % prof_steps) if graphed else (
+                                               "eager launches on %d HIP queues (camera / BEV chain%s%s)" % (
+                                                   1 + int(bool(getattr(wl.model, "lidar_side_stream", False))) + int(wl._wgrad_join is not None),
+                                                   ", LiDAR branch" if getattr(wl.model, "lidar_side_stream", False) else "",
+                                                   ", weight gradients" if wl._wgrad_join is not None else ""))
         if hasattr(wl, "vt_bf16"):
             line["config"]["view_transform_conv_dtype"] = "bf16" if wl.vt_bf16 else "fp32 (reference fp32 island)"
         if hasattr(wl, "n_params"):
