@@ -77,7 +77,7 @@ def _launch_wgrad(x, dy, weight, stride, pad, dil):
         if dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)
     # (no reference to dw is kept here: AccumulateGrad only takes a gradient over without a copy when nobody else holds it)
-    return dw
+    return dw, side
 
 
 class _NullCtx:
@@ -168,10 +168,15 @@ class _Conv2dFunction(torch.autograd.Function):
             ws = _workspace(x.device, lib.bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), stream)
             _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
                       W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
+        side = None
         if ctx.needs_input_grad[1]:
-            dw = _launch_wgrad(x, dy, weight, stride, pad, dil)
+            dw, side = _launch_wgrad(x, dy, weight, stride, pad, dil)
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
+            if side is not None:  # a leaf like dW: behind the weight gradient on the side stream (dy is kept alive by _KEEP)
+                with torch.cuda.stream(side):
+                    db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
+            else:
+                db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
         return dx, dw, db, None, None, None, None
 
 
@@ -205,7 +210,7 @@ class _LibConvHipWgradFunction(torch.autograd.Function):
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride] * 2, [pad] * 2, [dil] * 2, False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = _launch_wgrad(x, dy, weight, stride, pad, dil)
+            dw, _ = _launch_wgrad(x, dy, weight, stride, pad, dil)
         return dx, dw, None, None, None
 
 
