@@ -315,3 +315,37 @@ def test_camera_only_model_assembly_bf16(dev):
         grads = [p.grad for p in getattr(model, name).parameters() if p.requires_grad]
         assert any(g is not None and g.abs().sum() > 0 for g in grads), name
         assert all(g is None or torch.isfinite(g).all() for g in grads), name
+
+
+def test_direct_fused_adamw_equals_the_optimizer_object_and_skips_nonfinite_steps(dev, monkeypatch):
+    """amp.MasterWeightAdamW: the direct path (prepared lists -> torch's fused multi-tensor AdamW / norm kernels) and the path
+    through the torch.optim.AdamW object give the same parameters, bit for bit, over several clipped steps; a step whose
+    gradients are not finite changes nothing in either (parameters, moments, step counters)."""
+    import copy
+    from bevfusion_amd.amp import MasterWeightAdamW
+    torch.manual_seed(0)
+    base = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.BatchNorm2d(16), torch.nn.Conv2d(16, 8, 1),
+                               torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 5)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    nets, opts = [], []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("BFHIP_DIRECT_ADAMW", direct)
+        net = copy.deepcopy(base)
+        nets.append(net)
+        opts.append(MasterWeightAdamW(net, lr=1e-2, weight_decay=0.01, max_grad_norm=0.5, exclude=()))
+    assert opts[0].direct and not opts[1].direct
+    for step in range(5):
+        grads = [torch.randn(p.shape, generator=g, device=dev) * (3.0 if step % 2 else 0.01) for p in nets[0].parameters()]
+        if step == 3:
+            grads[0][0, 0, 0, 0] = float("nan")
+        before = [p.detach().clone() for p in nets[0].parameters()]
+        for net, opt in zip(nets, opts):
+            opt.zero_grad()
+            for p, gr in zip(net.parameters(), grads):
+                p.grad = gr.to(p.dtype).clone()
+            opt.step()
+        for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+            assert torch.equal(a, b), step
+        changed = any(not torch.equal(a, p.detach()) for a, p in zip(before, nets[0].parameters()))
+        assert changed == (step != 3), step
+    assert float(opts[0]._steps_flat[0]) == 4.0   # the skipped step did not advance the bias correction
