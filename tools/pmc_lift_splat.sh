@@ -13,15 +13,16 @@ for pass in A B C; do
   esac
   LS_ONLY=feat_bf16_out_bf16 timeout -k 10 170 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p -o c -- python3 tools/lift_splat_variants.py > $O/run_$pass.json 2> $O/run_$pass.err || { tail -3 $O/run_$pass.err; continue; }
   python3 - <<PY
-import csv, collections, glob
+import csv, collections, glob, re
 f = glob.glob("$O/p/**/c_counter_collection.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0]))) if f else []
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 first = None
 for r in rows:
     k = r["Kernel_Name"]
-    if "lift_splat" not in k: continue
-    k = k.split("(")[0][-34:]
+    m = re.search(r"lift_splat_(fwd|bwd)\w*(<\w+>)?", k)
+    if not m: continue
+    k = m.group(0)
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     first = first or r["Counter_Name"]
     if r["Counter_Name"] == first: n[k] += 1

@@ -10,13 +10,14 @@ for pass in A B; do
   else C="SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU"; fi
   BFHIP_WGRAD_WIDE=$wide timeout -k 10 170 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p -o c -- python3 tools/conv_micro.py $L > $O/run.json 2> $O/run.err || { tail -5 $O/run.err; exit 1; }
   python3 - <<PY
-import csv, collections
+import csv, collections, re
 rows = list(csv.DictReader(open("$O/p/c_counter_collection.csv")))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in rows:
     k = r["Kernel_Name"]
-    if "wgrad" not in k or "reduce" in k: continue
-    k = k.split("(")[0][-40:]
+    m = re.search(r"conv_wgrad\w*(<[^>]*>)?", k)
+    if not m or "reduce" in k: continue
+    k = m.group(0)
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVE_CYCLES": n[k] += 1
 for k, c in agg.items():
