@@ -136,8 +136,13 @@ class BatchNorm2dAct(_LazyBatchCounter, nn.BatchNorm2d):
         if self.fusable(x):
             self._pending_batches += 1
             partial = getattr(x, "_bfhip_stat_partial", None)  # statistics from the producing conv's epilogue (conv2d.py)
-            if partial is not None and (partial.shape[2] != x.shape[1] or partial.shape[0] != -(-(x.numel() // x.shape[1]) // 128)):
-                partial = None
+            if partial is not None:
+                partial, ptr, version = partial
+                # the sums describe the conv's output as it left the kernel: an in-place edit of x since then (add_, mul_, relu_)
+                # bumps the version counter, and the attribute must not survive it
+                if (ptr != x.data_ptr() or version != x._version or partial.shape[2] != x.shape[1]
+                        or partial.shape[0] != -(-(x.numel() // x.shape[1]) // 128)):
+                    partial = None
             return _apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
                           relu, partial)
         self._flush_batches()

@@ -251,7 +251,9 @@ class Conv2d(nn.Conv2d):
         emit = self.training and self.bias is None and torch.is_grad_enabled()
         y, partial = conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation), emit)
         if partial is not None:
-            y._bfhip_stat_partial = partial  # picked up by the fused BatchNorm that follows (bn2d.BatchNorm2dAct)
+            # picked up by the fused BatchNorm that follows (bn2d.BatchNorm2dAct), which checks that y is still the tensor the
+            # sums were taken from: same storage and no in-place edit since (tensor version counter)
+            y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
         return y
 
 

@@ -247,3 +247,24 @@ def test_weight_gradients_on_the_side_stream_are_identical(dev, monkeypatch):
     assert all(torch.isfinite(g.float()).all() and g.float().abs().sum() > 0 for g in grads[True])
     for a, b in zip(grads[False], grads[True]):
         assert torch.equal(a, b)
+
+
+def test_epilogue_statistics_do_not_survive_an_in_place_edit(dev):
+    """conv -> y.mul_(2) -> BatchNorm2dAct: the statistics the conv epilogue took describe y BEFORE the edit; the BatchNorm must
+    notice (tensor version counter) and run its own statistics pass -- result equal to a BatchNorm that never saw the attribute."""
+    from bevfusion_amd.bn2d import BatchNorm2dAct
+    torch.manual_seed(0)
+    conv = Conv2d(32, 64, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.randn(2, 32, 40, 44, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for strip in (False, True):
+        bn = BatchNorm2dAct(64, act=True).to(dev).train()
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            y = conv(x)
+        assert hasattr(y, "_bfhip_stat_partial")
+        y.mul_(2.0).add_(1.0)
+        if strip:
+            del y._bfhip_stat_partial
+        outs.append((bn(y).float(), bn.running_mean.clone(), bn.running_var.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
