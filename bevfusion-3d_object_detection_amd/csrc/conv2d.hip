@@ -959,8 +959,11 @@ int spconv_wgrad_tr(const void *in, const void *dout, const int32_t *pairs, int 
     (void)hipFuncSetAttribute((const void *)spconv_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_set = true;
   }
+  ProfScope ps_main;
+  prof_begin(BFHIP_OP_SPCONV_WGRAD_MAIN, stream, &ps_main);
   hipLaunchKernelGGL(spconv_wgrad_tr_kernel, dim3((unsigned)(sg.tiles_co * sg.tiles_k * sg.splits)), dim3(256), (size_t)4 * 64 * 256, stream,
                      (const bf16_t *)in, (const bf16_t *)dout, pairs, (float *)workspace, sg);
+  prof_end(&ps_main);
   const long long total = (long long)Cout * KV * Cin;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(total, 1024)), dim3(256), 0, stream, (const float *)workspace, sg.splits,
                      total, (void *)dW, 0);

@@ -2072,9 +2072,9 @@ BFHIP_EXPORT int bfhip_spconv_wgrad(const void *in, const void *dout, const int3
   static const int use_tr = getenv("BFHIP_SPCONV_WGRAD_FP32MFMA") ? 0 : 1;
   if (io_bf16 && use_tr && !perm && spconv_wgrad_tr_supported(KV, Cin, Cout)) {
     // bf16 features: the bf16-MFMA kernel (16x the matrix rate of the fp32-MFMA kernels below)
-    prof_begin(BFHIP_OP_SPCONV_WGRAD_MAIN, stream, &ps);
+    // (the BFHIP_OP_SPCONV_WGRAD_MAIN scope brackets the main kernel only, inside spconv_wgrad_tr: round 2 had it around the
+    // slab sum as well, which made the "main kernel" figure 26 % larger than the kernel's trace)
     int rc = spconv_wgrad_tr(in, dout, pairs, ld, KV, n_rows, Cin, Cout, dW, workspace, workspace_bytes, stream);
-    prof_end(&ps);
     prof_end(&ps_op);
     return rc != BFHIP_OK ? rc : check_launch("spconv_wgrad");
   }

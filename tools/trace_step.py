@@ -25,7 +25,9 @@ def category(n):
     return "other"
 
 
-def main(path, top=45):
+def main(path, top=45, which=-1):
+    """which: optimizer step to summarise, counted from the end (-1 = last; bench.py appends BENCH_ISOLATED_STEPS one-queue
+    steps behind the timed region, so the last TIMED step is -(isolated + 1))."""
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
@@ -36,7 +38,7 @@ def main(path, top=45):
             clusters.append([i])
         else:
             clusters[-1].append(i)
-    win = rows[clusters[-2][-1] + 1:clusters[-1][-1] + 1]
+    win = rows[clusters[which - 1][-1] + 1:clusters[which][-1] + 1]
     t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
     cat = collections.defaultdict(lambda: [0, 0])
     ker = collections.defaultdict(lambda: [0, 0])
@@ -78,4 +80,4 @@ def main(path, top=45):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 45)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 45, int(sys.argv[3]) if len(sys.argv) > 3 else -1)
