@@ -35,8 +35,16 @@ FAMILIES = {
 LIDAR = ("hard_voxelize", "spconv_fwd+spconv_bwd", "spconv_wgrad_main", "rulebook")
 
 
-def main(line_path, trace_path):
+def main(line_path, trace_path, plain_path=None):
     line = json.loads(open(line_path).read().strip().splitlines()[-1])
+    # optional: the bench line of a run WITHOUT the tracer (same code, same workload): event scopes are a few percent wider under
+    # rocprofv3, kernel durations are not, so the plain run's figures are the ones to hold against the kernel sums
+    plain = {}
+    if plain_path:
+        pl = json.loads(open(plain_path).read().strip().splitlines()[-1])
+        plain = {r["kernel"]: r.get("kernel_ms_per_step", r["ms_per_step"]) for r in pl["roofline_ops"]}
+        if "spconv_fwd" in plain and "spconv_bwd" in plain:
+            plain["spconv_fwd+spconv_bwd"] = plain["spconv_fwd"] + plain["spconv_bwd"]
     rows = list(csv.DictReader(open(trace_path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
@@ -65,8 +73,8 @@ def main(line_path, trace_path):
     print("columns: bench ms = HIP-event scope per step as printed by bench.py; kernels ms = sum of the op's kernel durations per step;\n"
           "span ms = per op instance, first kernel start -> last kernel end (what an event pair brackets: kernel time + the dispatch gaps\n"
           "between the op's own kernels, which tracing itself widens), summed per step; ratio = bench / span")
-    print("%-24s %-15s %10s %10s %10s %7s %9s   %s" % ("op", "bench figure", "bench ms", "kernels ms", "span ms", "ratio", "launches", "kernels"))
-    worst = 0.0
+    print("%-24s %-15s %10s %10s %10s %7s %11s %7s %9s   %s" % ("op", "bench figure", "bench ms", "kernels ms", "span ms", "ratio", "plain-run ms", "/kern", "launches", "kernels"))
+    worst = worst_plain = 0.0
     neutral = re.compile(r"__amd_rocclr_(fill|copy)Buffer")
     for op, pats in FAMILIES.items():
         if op not in bench:
@@ -109,9 +117,16 @@ def main(line_path, trace_path):
                 sp -= cut
         ratio = b / sp if sp else float("nan")
         worst = max(worst, abs(ratio - 1.0)) if sp else worst
-        print("%-24s %-15s %10.4f %10.4f %10.4f %7.2f %9.1f   %s" % (op, where, b, t, sp, ratio, cnt / n_steps, ", ".join("%s x%d" % (k, v // n_steps) for k, v in kn.most_common(4))))
-    print("largest deviation of a bench figure from its span in the trace: %.1f %%" % (100 * worst))
+        pr = plain.get(op)
+        if pr is not None and t:
+            worst_plain = max(worst_plain, abs(pr / t - 1.0))
+        print("%-24s %-15s %10.4f %10.4f %10.4f %7.2f %11s %7s %9.1f   %s" % (
+            op, where, b, t, sp, ratio, "%.4f" % pr if pr is not None else "-", "%.2f" % (pr / t) if (pr is not None and t) else "-",
+            cnt / n_steps, ", ".join("%s x%d" % (k, v // n_steps) for k, v in kn.most_common(4))))
+    print("largest deviation of a bench figure (this traced run) from its span in the trace: %.1f %%" % (100 * worst))
+    if plain:
+        print("largest deviation of a plain-run bench figure from the sum of its kernels' durations in the trace: %.1f %%" % (100 * worst_plain))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)

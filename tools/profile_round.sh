@@ -21,7 +21,7 @@ elif [ "$part" = B ]; then
   T=$(find $O/prof_full -name 'full_kernel_trace.csv' | head -1); S=$(find $O/prof_full -name 'full_kernel_stats.csv' | head -1)
   cp $S $O/bench_full_kernel_stats.csv
   python3 tools/trace_step.py $T 60 -6 > $O/bench_full_last_step_breakdown.txt   # last TIMED step (5 one-queue steps follow it)
-  python3 tools/check_roofline_vs_trace.py $O/bench_full_under_rocprof.json $T > $O/roofline_vs_trace.txt
+  python3 tools/check_roofline_vs_trace.py $O/bench_full_under_rocprof.json $T $( [ -f $O/bench_full.json ] && echo $O/bench_full.json ) > $O/roofline_vs_trace.txt
   rm -rf $O/prof_full
   run timeout -k 10 240 rocprofv3 --kernel-trace --output-format csv -d $O/prof_sp -o sp -- python3 tools/sparse_micro.py > $O/sparse_micro_under_rocprof.json 2> $O/prof_sp.err || exit 1
   python3 tools/sparse_pass_trace.py $(find $O/prof_sp -name 'sp_kernel_trace.csv' | head -1) > $O/sparse_pass.txt
