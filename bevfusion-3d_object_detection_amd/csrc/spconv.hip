@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace bfhip {
@@ -1612,10 +1613,48 @@ struct SortScratch {
     tmp_bytes = sort32_bytes(n_rows, 32);
     tmp = ws.take<char>(tmp_bytes);
   }
-  hipError_t sort(int n_rows, int KV, int32_t *perm, hipStream_t stream) {
-    return rocprim::radix_sort_pairs<RowSortConfig>(tmp, tmp_bytes, keys, keys_out, iota, (unsigned *)perm, (size_t)n_rows, 0, sort_bits(KV), stream);
-  }
+  hipError_t sort(int n_rows, int KV, int32_t *perm, hipStream_t stream);
 };
+
+// Round 3: the row order in ONE launch.  Rows are sorted by offset mask inside consecutive chunks of kSortChunk rows (a
+// chunk = a slab of space, rows being in voxel order); one 512-thread workgroup sorts one chunk in LDS (stable LSD radix,
+// rocprim::block_radix_sort), instead of a device-wide sort per rulebook -- which for these 10^5-row arrays was a block sort
+// plus 6-7 merge passes of ~5 us each, 12 times per LiDAR pass: 0.52 of the 1.15 ms the rulebooks cost.  The chunked order
+// keeps what the device-wide (eighth of the row range, mask) order was for: tiles of 16-64 consecutive sorted rows share
+// their offsets, and consecutive tiles stay in one slab of space (the gather-GEMM deals contiguous eighths of the tiles to
+// the 8 XCDs).
+constexpr int kSortChunk = 4096, kSortThreads = 512, kSortItems = kSortChunk / kSortThreads;
+
+__global__ __launch_bounds__(kSortThreads) void sort_rows_chunk_kernel(const unsigned *__restrict__ keys, int n_rows, int KV,
+                                                                      int *__restrict__ perm) {
+  using BlockSort = rocprim::block_radix_sort<unsigned, kSortThreads, kSortItems, unsigned>;
+  __shared__ typename BlockSort::storage_type storage;
+  const int base = blockIdx.x * kSortChunk;
+  const unsigned invalid = 1u << KV, low = invalid - 1u;  // rows beyond n_rows sort behind every real mask (KV <= 30)
+  unsigned k[kSortItems], v[kSortItems];
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const int idx = base + threadIdx.x * kSortItems + i;
+    k[i] = idx < n_rows ? (keys[idx] & low) : invalid;
+    v[i] = (unsigned)idx;
+  }
+  BlockSort().sort(k, v, storage, 0, KV + 1);
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const int pos = base + threadIdx.x * kSortItems + i;
+    if (pos < n_rows) perm[pos] = (int)v[i];
+  }
+}
+
+hipError_t SortScratch::sort(int n_rows, int KV, int32_t *perm, hipStream_t stream) {
+  static const int chunked = [] { const char *e = getenv("BFHIP_SPCONV_CHUNK_SORT"); return e ? atoi(e) : 1; }();
+  if (chunked && KV <= 30) {
+    hipLaunchKernelGGL(sort_rows_chunk_kernel, dim3(ceil_div(n_rows, kSortChunk)), dim3(kSortThreads), 0, stream, keys, n_rows, KV,
+                       perm);
+    return hipGetLastError();
+  }
+  return rocprim::radix_sort_pairs<RowSortConfig>(tmp, tmp_bytes, keys, keys_out, iota, (unsigned *)perm, (size_t)n_rows, 0, sort_bits(KV), stream);
+}
 }  // namespace
 
 // SubM rulebook.  row_mask / perm (optional, KV <= 32): the offset masks of the rows and their (region, mask)-sorted order, as

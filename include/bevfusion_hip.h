@@ -253,10 +253,12 @@ int bfhip_rulebook_sparse_fill(const int32_t *indices, int N, int B, const int *
                                void *workspace, size_t workspace_bytes, void *stream);
 /* mask_fwd / perm_fwd (over the output rows, from pair_fwd) and mask_bwd / perm_bwd (over the input rows, from pair_bwd):
  * optional, kernel volume <= 32; sort_workspace = bfhip_rulebook_sort_rows_workspace_bytes(max(N, n_out), KV) bytes. */
-/* row_mask[n] bit k = (pairs[k][n] >= 0); perm = rows stably sorted by (eighth of the row range, mask), so that the
- * 16 rows of an MFMA tile share their kernel offsets and whole offsets are skipped per tile (cf. spconv's
- * mask_argsort, projects/SparseConvolution/sparse_functional.py:139-162) while consecutive tiles stay in one slab of
- * space (the gather-GEMM deals contiguous eighths of the tiles to the 8 XCDs).  perm/row_mask are optional
+/* row_mask[n] bit k = (pairs[k][n] >= 0); perm = rows stably sorted by mask inside consecutive chunks of 4096 rows
+ * (key = (n / 4096, mask); one LDS sort per chunk, one launch), so that the 16 rows of an MFMA tile share their kernel
+ * offsets and whole offsets are skipped per tile (cf. spconv's mask_argsort,
+ * projects/SparseConvolution/sparse_functional.py:139-162) while consecutive tiles stay in one slab of space (the
+ * gather-GEMM deals contiguous eighths of the tiles to the 8 XCDs).  BFHIP_SPCONV_CHUNK_SORT=0: the round-2 order
+ * (eighth of the row range, mask) from a device-wide sort.  perm/row_mask are optional
  * (NULL) inputs of gemm / wgrad; results do not depend on them (only the fp32 summation order of wgrad). */
 size_t bfhip_rulebook_sort_rows_workspace_bytes(int n_rows, int KV);
 int bfhip_rulebook_sort_rows(const int32_t *pairs, int ld, int KV, int n_rows, uint32_t *row_mask,

@@ -564,15 +564,15 @@ def test_wgrad_abi_geometries_vs_fp64(dev, cin, cout, kv, n_rows, use_perm):
 
 
 def test_sort_rows_is_region_major_mask_sort(dev, sorted_rows):
-    """bfhip_rulebook_sort_rows: row_mask bit k = pair present; perm = stable sort by (eighth of the row range, mask)."""
+    """bfhip_rulebook_sort_rows: row_mask bit k = pair present; perm = stable sort by (chunk of 4096 rows, mask)."""
     from bevfusion_amd.spconv import sort_rows
     rs = np.random.RandomState(4)
-    for n, kv in ((1, 27), (777, 27), (5000, 27), (3000, 3)):
+    for n, kv in ((1, 27), (777, 27), (5000, 27), (3000, 3), (4096, 27), (4097, 27), (70000, 27)):
         pairs = np.where(rs.rand(kv, n) < 0.4, rs.randint(0, n, (kv, n)), -1).astype(np.int32)
         mask, perm = sort_rows(torch.from_numpy(pairs).to(dev))
         want_mask = ((pairs >= 0).astype(np.int64) << np.arange(kv)[:, None]).sum(0)
         np.testing.assert_array_equal(mask.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, want_mask)
-        key = ((np.arange(n, dtype=np.int64) * 8) // n << kv) | want_mask
+        key = ((np.arange(n, dtype=np.int64) // 4096) << kv) | want_mask
         np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind="stable"))
 
 
