@@ -59,6 +59,8 @@ class BEVFusion(nn.Module):
         self.bbox_head = build(bbox_head)
         self.lidar_side_stream = False  # opt-in: run the LiDAR branch on a second HIP stream (bench.py enables it)
         self._side_stream = None
+        # with the side stream: also run the image-independent prologue of the view transform there (BFHIP_SIDE_PREPARE=0: A/B)
+        self.side_prepare = os.environ.get("BFHIP_SIDE_PREPARE", "1") == "1"
         # static capacity mode of the LiDAR branch: buffers sized by (grow-only) bounds learnt from earlier frames, every row
         # count on the device, ZERO host reads per forward; the first forward runs the exact path to learn them.
         # Opt-in (BFHIP_STATIC_LIDAR=1, or a captured hipGraph, which needs it): on the side stream the two host reads of the
@@ -175,7 +177,7 @@ class BEVFusion(nn.Module):
 
     # ------------------------------------------------------------------ camera branch
     def extract_img_feat(self, x, points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
-                         lidar_aug_matrix, img_metas=None, geom_feats=None):
+                         lidar_aug_matrix, img_metas=None, geom_feats=None, prepared=None):
         B, N, C, H, W = x.size()
         x = self.img_backbone(x.reshape(B * N, C, H, W))
         x = self.img_neck(x)
@@ -187,6 +189,15 @@ class BEVFusion(nn.Module):
         # as they are instead of being widened to fp32 here and narrowed again in front of the first conv
         keep = getattr(self.view_transform, "conv_dtype", None) is not None and x.dtype == self.view_transform.conv_dtype
         with torch.autocast("cuda", enabled=False):  # fp32 island, as the reference (:177)
+            if prepared is not None:
+                prep, done = prepared
+                main = torch.cuda.current_stream(x.device)
+                main.wait_event(done)  # depth images, plan and dtransform features came from the side stream
+                for t in self.view_transform.prepared_tensors(prep):
+                    t.record_stream(main)
+                return self.view_transform(x if keep else x.float(), points, lidar2image, camera_intrinsics, camera2lidar,
+                                           img_aug_matrix, lidar_aug_matrix, img_metas, geom_feats_precomputed=geom_feats,
+                                           prepared=prep)
             return self.view_transform(x if keep else x.float(), points, lidar2image, camera_intrinsics, camera2lidar, img_aug_matrix,
                                        lidar_aug_matrix, img_metas, geom_feats_precomputed=geom_feats)
 
@@ -225,11 +236,25 @@ class BEVFusion(nn.Module):
                 else:
                     default = np.eye(4) if "aug" in key else None
                     mats[key] = imgs.new_tensor(np.asarray([m.get(meta_key, default) for m in batch_input_metas]))
+            prepared = None
+            if overlap and self.side_prepare and hasattr(self.view_transform, "prepare"):
+                # the part of the view transform that needs no image features -- sparse depth images, GT depth histogram, BEV plan,
+                # the dtransform conv stack (and, through autograd, its backward) -- runs on the side stream while the image
+                # backbone holds the main one; the LiDAR branch follows it there
+                side.wait_stream(torch.cuda.current_stream(imgs.device))  # (not `entry`: the matrices may have been built since)
+                with torch.cuda.stream(side), torch.autocast("cuda", enabled=False):
+                    prep = self.view_transform.prepare(imgs.shape[1], [p.float() for p in points], mats["lidar2img"],
+                                                       mats["cam2img"], mats["cam2lidar"], mats["img_aug_matrix"],
+                                                       mats["lidar_aug_matrix"],
+                                                       geom_feats_precomputed=batch_inputs_dict.get("geom_feats"))
+                    done = torch.cuda.Event()
+                    done.record(side)
+                prepared = (prep, done)
             # the reference passes deepcopy(points) because its rasteriser mutates them (:326); ours does not
             img_feature, depth_loss = self.extract_img_feat(imgs, points, mats["lidar2img"], mats["cam2img"],
                                                             mats["cam2lidar"], mats["img_aug_matrix"],
                                                             mats["lidar_aug_matrix"], batch_input_metas,
-                                                            geom_feats=batch_inputs_dict.get("geom_feats"))
+                                                            geom_feats=batch_inputs_dict.get("geom_feats"), prepared=prepared)
             features.append(img_feature)
         if overlap:
             # the sparse LiDAR kernels are small for the chip (a few hundred workgroups); on their own HIP stream they

@@ -376,7 +376,7 @@ class BaseDepthTransform(BaseViewTransform):
         if lidar_aug_matrix_inverse is None:
             lidar_aug_matrix_inverse = _inverse(lidar_aug_matrix)
         B = len(points)
-        N = img.shape[1]
+        N = img if isinstance(img, int) else img.shape[1]   # only the camera count is needed from the image tensor
         iH, iW = self.image_size
         fH, fW = self.feature_size
         dev = points[0].device
@@ -421,16 +421,42 @@ class BaseDepthTransform(BaseViewTransform):
         _lib.check(rc, "depth_histogram")
         return distr, counts
 
-    def forward(self, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix,
-                metas=None, camera_intrinsics_inverse=None, img_aug_matrix_inverse=None,
+    def prepare(self, n_cams, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix,
                 lidar_aug_matrix_inverse=None, geom_feats_precomputed=None):
-        depth_img, counts = self.rasterise_depth(img, points, lidar2image, img_aug_matrix, lidar_aug_matrix,
+        """Everything of forward() that does not need the image features: sparse depth images + GT depth histogram
+        (reference :372-449,636-686), the BEV plan (:68-176) and, in DepthLSSTransform, the dtransform conv stack on the depth
+        images (:581-591).  The detector runs it on the LiDAR side stream while the image backbone occupies the main one
+        (bevfusion.BEVFusion.extract_feat); forward(..., prepared=...) then starts at the depthnet."""
+        depth_img, counts = self.rasterise_depth(n_cams, points, lidar2image, img_aug_matrix, lidar_aug_matrix,
                                                  lidar_aug_matrix_inverse, with_histogram=True)
         if isinstance(geom_feats_precomputed, BevPlan):
             plan = geom_feats_precomputed
         else:
             plan = self.make_plan(**self._calibration(cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix))
-        depth, feat, est_depth_distr, gt_depth_distr, counts_3d = self.get_depth_and_feat(img, depth_img, counts)
+        prep = dict(depth_img=depth_img, counts=counts, plan=plan)
+        prep.update(self.prepare_depth(depth_img, counts))
+        return prep
+
+    def prepare_depth(self, depth_img, counts):
+        return {}
+
+    @staticmethod
+    def prepared_tensors(prep):
+        """Every tensor a `prepare()` result holds (for record_stream when it was produced on another stream)."""
+        out = [v for v in prep.values() if torch.is_tensor(v)]
+        plan = prep.get("plan")
+        if plan is not None:
+            out += [v for v in vars(plan).values() if torch.is_tensor(v)]
+        return out
+
+    def forward(self, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix,
+                metas=None, camera_intrinsics_inverse=None, img_aug_matrix_inverse=None,
+                lidar_aug_matrix_inverse=None, geom_feats_precomputed=None, prepared=None):
+        if prepared is None:
+            prepared = self.prepare(img.shape[1], points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix,
+                                    lidar_aug_matrix, lidar_aug_matrix_inverse, geom_feats_precomputed)
+        depth_img, counts, plan = prepared["depth_img"], prepared["counts"], prepared["plan"]
+        depth, feat, est_depth_distr, gt_depth_distr, counts_3d = self.get_depth_and_feat(img, depth_img, counts, prepared)
         x = self.lift_splat_bev(depth, feat, plan)
         if self.training:
             # depth cross-entropy on cells that hold LiDAR returns (reference :540-547)
@@ -484,17 +510,27 @@ class DepthLSSTransform(BaseDepthTransform):
         fH, fW = self.feature_size
         return distr.view(B, N, fH, fW, self.D), counts.view(B, N, fH, fW, self.D)
 
-    def get_depth_and_feat(self, x, d, counts=None):
-        B, N, C, fH, fW = x.shape
-        BN = B * N
-        d = d.reshape(BN, *d.shape[2:])
-        x = x.reshape(BN, C, fH, fW)
+    def prepare_depth(self, depth_img, counts):
+        """GT depth distribution + dtransform features of the sparse depth images (no image features needed)."""
+        B, N = depth_img.shape[:2]
+        d = depth_img.reshape(B * N, *depth_img.shape[2:])
         if counts is not None:  # accumulated by the rasteriser in the same pass
             gt_depth_distr, counts_3d = self.depth_distribution(counts=counts)
         else:
             gt_depth_distr, counts_3d = self.gt_depth_distribution(d, B, N)
         with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
-            x = self.depthnet(torch.cat([self.run_dtransform(d), x], dim=1))
+            dfeat = self.run_dtransform(d)
+        return dict(gt_depth_distr=gt_depth_distr, counts_3d=counts_3d, dfeat=dfeat)
+
+    def get_depth_and_feat(self, x, d, counts=None, prepared=None):
+        B, N, C, fH, fW = x.shape
+        BN = B * N
+        x = x.reshape(BN, C, fH, fW)
+        if prepared is None or "dfeat" not in prepared:
+            prepared = self.prepare_depth(d, counts)
+        gt_depth_distr, counts_3d, dfeat = prepared["gt_depth_distr"], prepared["counts_3d"], prepared["dfeat"]
+        with torch.autocast("cuda", dtype=self.conv_dtype or torch.bfloat16, enabled=self.conv_dtype is not None):
+            x = self.depthnet(torch.cat([dfeat, x], dim=1))
         if BF16_FEAT and x.dtype == torch.bfloat16 and x.is_cuda and self.C % 8 == 0:
             # the reference widens the whole [BN, D + C, fH, fW] tensor (x = x.float()).  Same values, less traffic: only the D
             # depth logits are widened (the softmax runs in fp32); the C feature channels stay as the bf16 convolution stored
