@@ -459,15 +459,29 @@ class BaseDepthTransform(BaseViewTransform):
         depth, feat, est_depth_distr, gt_depth_distr, counts_3d = self.get_depth_and_feat(img, depth_img, counts, prepared)
         x = self.lift_splat_bev(depth, feat, plan)
         if self.training:
-            # depth cross-entropy on cells that hold LiDAR returns (reference :540-547)
-            mask_flat = counts_3d.sum(dim=-1).view(-1) > 0
-            gt = gt_depth_distr.view(-1, self.D)
-            est = est_depth_distr.reshape(-1, self.D)
-            cross_ent = -torch.sum(gt * torch.log(est + 1e-8), dim=-1)
-            depth_loss = torch.sum(cross_ent * mask_flat.float()) / (mask_flat.sum() + 1e-8)
+            # depth cross-entropy on cells that hold LiDAR returns (reference :540-547).  The reference computes it and never adds
+            # it to the losses (BF/bevfusion.py:388-392), so nothing downstream waits for it: with an auxiliary stream (set by the
+            # detector in two-stream mode, joined where the LiDAR branch is joined) its half-dozen passes over [P, D] leave the
+            # main queue
+            aux = getattr(self, "aux_stream", None)
+            if aux is not None and est_depth_distr.is_cuda:
+                aux.wait_stream(torch.cuda.current_stream(est_depth_distr.device))
+                for t in (est_depth_distr, gt_depth_distr, counts_3d):
+                    t.record_stream(aux)
+                with torch.cuda.stream(aux):
+                    depth_loss = self._depth_loss(est_depth_distr, gt_depth_distr, counts_3d)
+            else:
+                depth_loss = self._depth_loss(est_depth_distr, gt_depth_distr, counts_3d)
         else:
             depth_loss = 0.0
         return x, depth_loss
+
+    def _depth_loss(self, est_depth_distr, gt_depth_distr, counts_3d):
+        mask_flat = counts_3d.sum(dim=-1).view(-1) > 0
+        gt = gt_depth_distr.view(-1, self.D)
+        est = est_depth_distr.reshape(-1, self.D)
+        cross_ent = -torch.sum(gt * torch.log(est + 1e-8), dim=-1)
+        return torch.sum(cross_ent * mask_flat.float()) / (mask_flat.sum() + 1e-8)
 
 
 @MODELS.register_module()
