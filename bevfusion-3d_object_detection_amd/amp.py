@@ -58,7 +58,13 @@ class MasterWeightAdamW:
         # called on lists prepared ONCE -- the optimizer object re-derives its per-parameter lists, state dicts and device
         # groups in Python on every step (2.8 ms of host time per step for the ~450 tensors of this model, on a step whose host
         # and GPU sides are balanced).  Same arithmetic, same found_inf skip; BFHIP_DIRECT_ADAMW=0 goes through the object.
-        self.direct = os.environ.get("BFHIP_DIRECT_ADAMW", "1") == "1" and not capturable
+        # Flat path (default, csrc/optim.hip): clipping + AdamW + the bf16 refresh of ALL tensors in three launches from a
+        # device-resident table; per step only the gradient pointers are uploaded.  BFHIP_FLAT_ADAMW=0 selects the paths below.
+        self.flat = (os.environ.get("BFHIP_FLAT_ADAMW", "1") == "1" and not capturable and max_grad_norm is not None
+                     and all(p.is_cuda for p in self.master + self.other))
+        if self.flat:
+            self._build_flat(lr, weight_decay)
+        self.direct = os.environ.get("BFHIP_DIRECT_ADAMW", "1") == "1" and not capturable and not self.flat
         if self.direct:
             self._params = self.master + self.other
             dev = self._params[0].device
@@ -69,6 +75,69 @@ class MasterWeightAdamW:
             g = self.opt.param_groups[0]
             self._hyper = dict(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], weight_decay=g["weight_decay"], eps=g["eps"])
 
+    # ------------------------------------------------------------------ flat path
+    def _build_flat(self, lr, weight_decay):
+        import numpy as np
+        from . import _lib
+        lib = _lib.load()
+        g = self.opt.param_groups[0]
+        self._hyper_flat = (float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(weight_decay))
+        dev = self.master[0].device if self.master else self.other[0].device
+        # (parameter whose .grad is read, fp32 master, bf16 copy or None)
+        self._flat_items = [(p, m, p) for p, m in zip(self.low, self.master)] + [(p, p.data, None) for p in self.other]
+        for _, m, _ in self._flat_items:
+            assert m.dtype == torch.float32
+        self._flat_m = [torch.zeros_like(m, memory_format=torch.preserve_format) for _, m, _ in self._flat_items]
+        self._flat_v = [torch.zeros_like(m, memory_format=torch.preserve_format) for _, m, _ in self._flat_items]
+        seg_dt = np.dtype([("master", "<u8"), ("m", "<u8"), ("v", "<u8"), ("lowp", "<u8"), ("n", "<i8"), ("grad_bf16", "<i4"),
+                           ("pad", "<i4")])
+        assert seg_dt.itemsize == lib.bfhip_adamw_segment_bytes()
+        chunk = lib.bfhip_adamw_chunk_elems()
+        segs = np.zeros(len(self._flat_items), seg_dt)
+        chunks = []
+        for i, ((p, m, low), em, ev) in enumerate(zip(self._flat_items, self._flat_m, self._flat_v)):
+            # element i of every array of a record must be the same logical element: all share the parameter's dense layout
+            assert em.stride() == m.stride() and (low is None or low.stride() == m.stride()), "layout mismatch"
+            segs[i] = (m.data_ptr(), em.data_ptr(), ev.data_ptr(), low.data_ptr() if low is not None else 0, m.numel(),
+                       1 if low is not None else 0, 0)
+            chunks += [(i, c) for c in range(-(-m.numel() // chunk))]
+        self._n_chunks = len(chunks)
+        self._segs_dev = torch.from_numpy(segs.view(np.uint8).copy()).to(dev)
+        self._chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev)
+        self._partial_dev = torch.empty(self._n_chunks, dtype=torch.float32, device=dev)
+        self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)  # [0] clip, [1] found_inf, [2] step, [5] gradient norm
+        n = len(self._flat_items)
+        self._gptr_host = [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(2)]  # alternating: a copy may be in flight
+        self._gptr_np = [t.numpy() for t in self._gptr_host]
+        self._gptr_dev = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._flip = 0
+        self._grad_dtype = [torch.bfloat16 if low is not None else torch.float32 for _, _, low in self._flat_items]
+
+    def _step_flat(self):
+        from . import _lib
+        ptrs, keep = [], []
+        for (p, m, _), dt in zip(self._flat_items, self._grad_dtype):
+            g = p.grad
+            if g is None:
+                ptrs.append(0)
+                continue
+            if g.dtype != dt or g.stride() != m.stride():
+                # a gradient that is not laid out like its parameter (or not in its dtype): one conforming copy
+                c = torch.empty_strided(m.size(), m.stride(), dtype=dt, device=m.device)
+                c.copy_(g)
+                keep.append(c)
+                g = c
+            ptrs.append(g.data_ptr())
+        k = self._flip
+        self._flip ^= 1
+        self._gptr_np[k][:] = ptrs
+        self._gptr_dev.copy_(self._gptr_host[k], non_blocking=True)
+        lr, b1, b2, eps, wd = self._hyper_flat
+        _lib.call("bfhip_adamw_step", self._segs_dev.data_ptr(), self._gptr_dev.data_ptr(), self._chunks_dev.data_ptr(), self._n_chunks,
+                  self._partial_dev.data_ptr(), self.scalars.data_ptr(), lr, b1, b2, eps, wd, float(self.max_grad_norm),
+                  _lib.stream_of(self._gptr_dev))
+        self._keep = keep  # conforming copies stay alive until the next step (the kernels read them asynchronously)
+
     def zero_grad(self):
         for p in self.low:
             p.grad = None
@@ -77,6 +146,8 @@ class MasterWeightAdamW:
 
     @torch.no_grad()
     def step(self):
+        if self.flat:
+            return self._step_flat()
         have = [(m.grad, p.grad) for m, p in zip(self.master, self.low) if p.grad is not None]
         if have:
             torch._foreach_copy_([a for a, _ in have], [b for _, b in have])  # bf16 -> fp32, one multi-tensor kernel

@@ -496,6 +496,25 @@ int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *ga
                             int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
                             float *stats, void *y, const float *partial, int nblk, const int32_t *m_dev, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * gradient clipping + AdamW + bf16 parameter refresh of all parameter tensors in three launches
+ *   (replaces, in the benchmarked training step, clip_grad_norm_ + torch.optim.AdamW of the reference's optim_wrapper,
+ *   projects/BEVFusion/configs/nuscenes/bevfusion_lidar_voxel0075_second_secfpn_8xb4-cyclic-20e_nus-3d.py:369-372)
+ *   segs_dev      : n_tensors records of bfhip_adamw_segment_bytes() bytes each:
+ *                   { float *master, *m, *v; uint16_t *lowp (bf16 copy or NULL); int64 n; int32 grad_bf16, pad }
+ *   grad_ptrs_dev : int64[n_tensors] device addresses of this step's gradients (0: no gradient = zero gradient), element
+ *                   order = the parameter's own memory order
+ *   chunks_dev    : int32[n_chunks][2] = (tensor, chunk index) covering every tensor in chunks of bfhip_adamw_chunk_elems()
+ *   partial_dev   : f32[n_chunks] scratch; scalars_dev : f32[8] persistent state ([2] = step count; zero it once):
+ *                   after the call [0] clip scale, [1] 1 if the gradient norm was NaN / inf (nothing was updated), [5] the norm
+ *   max_norm <= 0 : no clipping.  Arithmetic: torch's fused AdamW (decoupled weight decay, fp32), bf16 copy rounded once.
+ * --------------------------------------------------------------------------------------- */
+int bfhip_adamw_segment_bytes(void);
+int bfhip_adamw_chunk_elems(void);
+int bfhip_adamw_step(const void *segs_dev, const int64_t *grad_ptrs_dev, const int32_t *chunks_dev, int n_chunks,
+                     float *partial_dev, float *scalars_dev, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, float max_norm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

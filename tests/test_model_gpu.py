@@ -317,35 +317,48 @@ def test_camera_only_model_assembly_bf16(dev):
         assert all(g is None or torch.isfinite(g).all() for g in grads), name
 
 
-def test_direct_fused_adamw_equals_the_optimizer_object_and_skips_nonfinite_steps(dev, monkeypatch):
-    """amp.MasterWeightAdamW: the direct path (prepared lists -> torch's fused multi-tensor AdamW / norm kernels) and the path
-    through the torch.optim.AdamW object give the same parameters, bit for bit, over several clipped steps; a step whose
-    gradients are not finite changes nothing in either (parameters, moments, step counters)."""
+def test_optimizer_paths_agree_and_skip_nonfinite_steps(dev, monkeypatch):
+    """amp.MasterWeightAdamW, three paths over the same clipped steps: (i) through the torch.optim.AdamW object, (ii) direct calls of
+    torch's fused multi-tensor kernels on prepared lists -- bit-identical to (i) --, (iii) the flat three-launch path of
+    csrc/optim.hip (bfhip_adamw_step) -- the same fp32 arithmetic with its own reduction order for the gradient norm: master
+    weights within 2e-6 relative, bf16 copies within one bf16 step.  A step whose gradients are not finite changes nothing in any of
+    them (parameters, moments, step counters)."""
     import copy
     from bevfusion_amd.amp import MasterWeightAdamW
     torch.manual_seed(0)
     base = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.BatchNorm2d(16), torch.nn.Conv2d(16, 8, 1),
-                               torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 5)).to(dev)
+                               torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 5)).to(dev).to(memory_format=torch.channels_last)
     g = torch.Generator(device=dev).manual_seed(1)
     nets, opts = [], []
-    for direct in ("1", "0"):
+    for flat, direct in (("1", "1"), ("0", "1"), ("0", "0")):
+        monkeypatch.setenv("BFHIP_FLAT_ADAMW", flat)
         monkeypatch.setenv("BFHIP_DIRECT_ADAMW", direct)
         net = copy.deepcopy(base)
         nets.append(net)
         opts.append(MasterWeightAdamW(net, lr=1e-2, weight_decay=0.01, max_grad_norm=0.5, exclude=()))
-    assert opts[0].direct and not opts[1].direct
-    for step in range(5):
+    assert opts[0].flat and opts[1].direct and not (opts[2].flat or opts[2].direct)
+    for step in range(6):
         grads = [torch.randn(p.shape, generator=g, device=dev) * (3.0 if step % 2 else 0.01) for p in nets[0].parameters()]
         if step == 3:
             grads[0][0, 0, 0, 0] = float("nan")
-        before = [p.detach().clone() for p in nets[0].parameters()]
+        if step == 4:
+            grads[2] = None                         # a parameter that took no part in the step: zero gradient in every path
+        before = [[p.detach().clone() for p in net.parameters()] for net in nets]
         for net, opt in zip(nets, opts):
             opt.zero_grad()
             for p, gr in zip(net.parameters(), grads):
-                p.grad = gr.to(p.dtype).clone()
+                if gr is not None:
+                    p.grad = gr.to(p.dtype).clone(memory_format=torch.preserve_format)
             opt.step()
-        for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+        for a, b in zip(nets[1].parameters(), nets[2].parameters()):
             assert torch.equal(a, b), step
-        changed = any(not torch.equal(a, p.detach()) for a, p in zip(before, nets[0].parameters()))
-        assert changed == (step != 3), step
-    assert float(opts[0]._steps_flat[0]) == 4.0   # the skipped step did not advance the bias correction
+        for a, b in zip(opts[0].master, opts[2].master):     # fp32 masters of the bf16 parameters
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-8), (step, float((a - b).abs().max()))
+        for a, b in zip(nets[0].parameters(), nets[2].parameters()):
+            tol = 2e-6 if a.dtype == torch.float32 else 2 ** -7
+            assert torch.allclose(a.float(), b.float(), rtol=tol, atol=1e-8), step
+        for net, bef in zip(nets, before):
+            changed = any(not torch.equal(a, p.detach()) for a, p in zip(bef, net.parameters()))
+            assert changed == (step != 3), step
+    assert float(opts[1]._steps_flat[0]) == 5.0 and float(opts[0].scalars[2]) == 5.0   # the skipped step did not count
+    assert float(opts[0].scalars[1]) == 0.0 and float(opts[0].scalars[5]) > 0.0
