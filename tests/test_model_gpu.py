@@ -353,10 +353,10 @@ def test_optimizer_paths_agree_and_skip_nonfinite_steps(dev, monkeypatch):
         for a, b in zip(nets[1].parameters(), nets[2].parameters()):
             assert torch.equal(a, b), step
         for a, b in zip(opts[0].master, opts[2].master):     # fp32 masters of the bf16 parameters
-            assert torch.allclose(a, b, rtol=2e-6, atol=1e-8), (step, float((a - b).abs().max()))
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (step, float((a - b).abs().max()))
         for a, b in zip(nets[0].parameters(), nets[2].parameters()):
-            tol = 2e-6 if a.dtype == torch.float32 else 2 ** -7
-            assert torch.allclose(a.float(), b.float(), rtol=tol, atol=1e-8), step
+            tol = 1e-5 if a.dtype == torch.float32 else 2 ** -7
+            assert torch.allclose(a.float(), b.float(), rtol=tol, atol=1e-7), step
         for net, bef in zip(nets, before):
             changed = any(not torch.equal(a, p.detach()) for a, p in zip(bef, net.parameters()))
             assert changed == (step != 3), step
