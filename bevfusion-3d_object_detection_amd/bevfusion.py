@@ -237,8 +237,6 @@ class BEVFusion(nn.Module):
                     default = np.eye(4) if "aug" in key else None
                     mats[key] = imgs.new_tensor(np.asarray([m.get(meta_key, default) for m in batch_input_metas]))
             prepared = None
-            if hasattr(self.view_transform, "prepare"):  # leaf work of the view transform (depth loss) goes to the side stream too
-                self.view_transform.aux_stream = side if (overlap and self.side_prepare) else None
             if overlap and self.side_prepare and hasattr(self.view_transform, "prepare"):
                 # the part of the view transform that needs no image features -- sparse depth images, GT depth histogram, BEV plan,
                 # the dtransform conv stack (and, through autograd, its backward) -- runs on the side stream while the image

@@ -460,9 +460,10 @@ class BaseDepthTransform(BaseViewTransform):
         x = self.lift_splat_bev(depth, feat, plan)
         if self.training:
             # depth cross-entropy on cells that hold LiDAR returns (reference :540-547).  The reference computes it and never adds
-            # it to the losses (BF/bevfusion.py:388-392), so nothing downstream waits for it: with an auxiliary stream (set by the
-            # detector in two-stream mode, joined where the LiDAR branch is joined) its half-dozen passes over [P, D] leave the
-            # main queue
+            # it to the losses (BF/bevfusion.py:388-392), so nothing downstream waits for it: with an auxiliary stream its half-dozen
+            # passes over [P, D] leave the main queue.  The stream must NOT be the LiDAR side stream: waiting for the main stream
+            # here would hold the LiDAR branch, queued behind it, until the camera forward has finished (measured: +3 ms per
+            # step); `aux_stream` is left unset by the detector
             aux = getattr(self, "aux_stream", None)
             if aux is not None and est_depth_distr.is_cuda:
                 aux.wait_stream(torch.cuda.current_stream(est_depth_distr.device))
