@@ -721,7 +721,8 @@ def main():
         model = getattr(wl, "model", None)
         from bevfusion_amd import conv2d as _c2
         overlapped = bool(model is not None and (getattr(model, "lidar_side_stream", False) or _c2.WGRAD_SIDE_STREAM))
-        if ISOLATED_STEPS > 0 and not graphed and overlapped and rank == 0:
+        # single process only: a step contains the gradient exchange, so with several ranks every rank would have to run it
+        if ISOLATED_STEPS > 0 and not graphed and overlapped and dist is None:
             # kernel-time pass: the same workload on ONE queue (LiDAR branch and weight gradients in line), every op timed.
             # Outside the timed region.
             side_lidar, side_wgrad = model.lidar_side_stream, _c2.WGRAD_SIDE_STREAM
