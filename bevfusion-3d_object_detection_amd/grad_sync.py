@@ -67,6 +67,9 @@ class FlatGradAllReduce:
         self.group = group
         self.world = dist.get_world_size(group)
         self.exchange = exchange or os.environ.get("BFHIP_GRAD_EXCHANGE", "a2a")
+        # hand the reduced gradients over as views of the flat buffer instead of copying them back into the autograd tensors
+        # (valid for callers that clear .grad before the next backward, as the optimizers of this package do)
+        self.alias_grads = os.environ.get("BFHIP_GRAD_ALIAS", "1") == "1"
         assert self.exchange in ("a2a", "allreduce_fp32", "allreduce_bf16"), self.exchange
         params = list(params)
         if self.exchange == "a2a" and self.world > 1:
@@ -161,6 +164,12 @@ class FlatGradAllReduce:
             else:
                 torch._foreach_copy_(views, grads)
             self._mean_over_ranks(flat)
+            if self.alias_grads:
+                # p.grad := the parameter's slice of the flat buffer (laid out like the parameter): no copy back.  The buffer is
+                # overwritten by the next reduce(), i.e. after the optimizer has consumed these gradients.
+                for p, v in zip(ps, views):
+                    p.grad = v
+                continue
             for i, g in enumerate(grads):
                 if g is None:
                     ps[i].grad = views[i].clone()
