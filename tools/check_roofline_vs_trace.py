@@ -49,7 +49,7 @@ def main(line_path, trace_path, plain_path=None):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
     # optimizer steps = clusters of the fused AdamW launches
-    adam = [i for i, n in enumerate(names) if "FusedOptimizer" in n or ("multi_tensor_apply" in n and "Adam" in n)]
+    adam = [i for i, n in enumerate(names) if "adamw_update_kernel" in n or "FusedOptimizer" in n or ("multi_tensor_apply" in n and "Adam" in n)]
     ends = []
     for i in adam:
         if ends and i - ends[-1] < 50:

@@ -7,6 +7,8 @@ import sys
 
 
 def category(n):
+    if "adamw_" in n:
+        return "optimizer"
     if "bfhip" in n:
         return "bfhip:" + re.sub(r".*::", "", n.split("(")[0])[:34]
     low = n.lower()
@@ -16,7 +18,7 @@ def category(n):
         return "batchnorm"
     if "attn" in n or "bwd_kernel" in n:
         return "attention"
-    if "multi_tensor" in n:
+    if "multi_tensor" in n or "adamw_" in n:
         return "optimizer"
     if "elementwise" in n or "SubTensor" in n or "copy" in low or "fill" in low:
         return "elementwise/copy/fill"
@@ -31,7 +33,9 @@ def main(path, top=45, which=-1):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
-    adam = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
+    adam = [i for i, n in enumerate(names) if "adamw_update_kernel" in n]  # the flat optimizer step (csrc/optim.hip) ends a step
+    if not adam:
+        adam = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
     clusters = []
     for i in adam:
         if not clusters or i - clusters[-1][-1] > 50:
