@@ -17,11 +17,13 @@ if [ "$part" = A ]; then
   BFHIP_SPCONV_SORT=0 run timeout -k 10 200 python3 bench.py --no-cpu-baseline > $O/bench_full_nosort.json 2> $O/bench_nosort.err || exit 1
 elif [ "$part" = B ]; then
   export BENCH_REFERENCE_NUMERICS=0
+  # the same command without the tracer first: its figures are what the kernel sums of the trace are held against
+  run timeout -k 10 300 python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/bench_full_plain_same_box.json 2> $O/plain.err || exit 1
   run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_full -o full -- python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/bench_full_under_rocprof.json 2> $O/prof_full.err || exit 1
   T=$(find $O/prof_full -name 'full_kernel_trace.csv' | head -1); S=$(find $O/prof_full -name 'full_kernel_stats.csv' | head -1)
   cp $S $O/bench_full_kernel_stats.csv
   python3 tools/trace_step.py $T 60 -6 > $O/bench_full_last_step_breakdown.txt   # last TIMED step (5 one-queue steps follow it)
-  python3 tools/check_roofline_vs_trace.py $O/bench_full_under_rocprof.json $T $( [ -f $O/bench_full.json ] && echo $O/bench_full.json ) > $O/roofline_vs_trace.txt
+  python3 tools/check_roofline_vs_trace.py $O/bench_full_under_rocprof.json $T $O/bench_full_plain_same_box.json > $O/roofline_vs_trace.txt
   rm -rf $O/prof_full
   run timeout -k 10 240 rocprofv3 --kernel-trace --output-format csv -d $O/prof_sp -o sp -- python3 tools/sparse_micro.py > $O/sparse_micro_under_rocprof.json 2> $O/prof_sp.err || exit 1
   python3 tools/sparse_pass_trace.py $(find $O/prof_sp -name 'sp_kernel_trace.csv' | head -1) > $O/sparse_pass.txt
