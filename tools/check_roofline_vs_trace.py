@@ -23,7 +23,7 @@ FAMILIES = {
     "spconv_wgrad_main": [r"spconv_wgrad"],
     "rulebook": [r"fill_pair_kernel", r"subm_insert_kernel", r"subm_pairs", r"sparse_mark_kernel", r"words_count_kernel",
                  r"blocks_scan_kernel", r"words_prefix_kernel", r"sparse_out_indices_kernel", r"sparse_pairs", r"row_mask_kernel",
-                 r"merge_sort|block_sort|wrapped_merge"],
+                 r"merge_sort|block_sort|wrapped_merge", r"sort_rows_chunk_kernel"],
     "lift_splat_fwd": [r"lift_splat_fwd"],
     "lift_splat_bwd": [r"lift_splat_bwd"],
     "conv2d_fwd": [r"conv_igemm_kernel<[^>]*, 0>"],
@@ -89,7 +89,6 @@ def main(line_path, trace_path, plain_path=None):
                 tot += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 cnt += 1
                 kn[re.sub(r".*::", "", r["Kernel_Name"].split("(")[0])[:28]] += 1
-        t = tot / 1e6 / n_steps
         # spans: per queue, maximal runs of the op's kernels (runtime memset / copy kernels in between do not break a run)
         span = 0
         by_q = collections.defaultdict(list)
@@ -97,16 +96,24 @@ def main(line_path, trace_path, plain_path=None):
             by_q[r.get("Queue_Id", "0")].append(r)
         for q_rows in by_q.values():
             first = last = None
+            pending = 0  # runtime fill / copy kernels seen since the run's last own kernel: the op's own memsets when the run goes on
             for r in q_rows:
                 fam = any(re.search(p, r["Kernel_Name"]) for p in pats)
                 if fam:
                     first = first if first is not None else int(r["Start_Timestamp"])
                     last = int(r["End_Timestamp"])
-                elif not neutral.search(r["Kernel_Name"]) and first is not None:
+                    tot += pending
+                    pending = 0
+                elif neutral.search(r["Kernel_Name"]):
+                    if first is not None:
+                        pending += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                elif first is not None:
                     span += last - first
                     first = last = None
+                    pending = 0
             if first is not None:
                 span += last - first
+        t = tot / 1e6 / n_steps  # own kernels + the runtime memsets between them
         sp = span / 1e6 / n_steps
         if op == "conv2d_wgrad" and "spconv_wgrad_main" in bench:  # remove the sparse layers' share of the shared slab-sum kernel
             red = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[lo:hi] if "conv_wgrad_reduce_kernel" in r["Kernel_Name"]]
