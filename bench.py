@@ -390,13 +390,17 @@ class _ModelWorkload:
         convs, bns, hybrid = [], [], []
         orig_c, orig_b, orig_h = c2._Conv2dFunction.forward, b2._apply, c2._LibConvHipWgradFunction.forward
 
-        def spy_c(ctx, x, weight, bias, stride, pad, dil, emit_stats):
+        def shape(x, weight, stride, pad, dil):
             N, Cin, H, W = x.shape
             Cout, _, KH, KW = weight.shape
             OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
             OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-            convs.append((N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin))
-            return orig_c(ctx, x, weight, bias, stride, pad, dil, emit_stats)
+            return (N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin)
+
+        # every entry: (M, K, Cout, data gradient wanted, input elements, forward on HIP, data gradient on HIP)
+        def spy_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib=False):
+            convs.append(shape(x, weight, stride, pad, dil) + (True, not dgrad_lib))
+            return orig_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib)
 
         def spy_b(x, residual, *a, **k):
             if x.is_cuda and x.dim() == 4:
@@ -404,13 +408,10 @@ class _ModelWorkload:
                 bns.append((x.numel() * x.element_size(), residual is not None, has_partial))
             return orig_b(x, residual, *a, **k)
 
-        def spy_h(ctx, x, weight, stride, pad, dil):  # library forward / data gradient, HIP weight gradient (ResNet-50 trunk)
-            N, Cin, H, W = x.shape
-            Cout, _, KH, KW = weight.shape
-            OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
-            OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-            hybrid.append((N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin))
-            return orig_h(ctx, x, weight, stride, pad, dil)
+        def spy_h(ctx, x, weight, stride, pad, dil, dgrad_hip=False):  # library forward, HIP weight gradient (ResNet-50 trunk)
+            convs.append(shape(x, weight, stride, pad, dil) + (False, bool(dgrad_hip)))
+            hybrid.append(1)
+            return orig_h(ctx, x, weight, stride, pad, dil, dgrad_hip)
 
         c2._Conv2dFunction.forward, b2._apply = staticmethod(spy_c), spy_b
         c2._LibConvHipWgradFunction.forward = staticmethod(spy_h)
@@ -423,18 +424,19 @@ class _ModelWorkload:
         work = {}
         peak, note = MFMA_PEAK_BF16
 
-        def conv_entry(sel, scope, extra=()):
-            rows = [c for c in convs if sel(c)] + list(extra)
-            fl = sum(2.0 * m * k * co for m, k, co, _, _ in rows)
-            by = sum((xin + m * co + k * co) * 2 for m, k, co, _, xin in rows)
+        def conv_entry(sel, scope):
+            rows = [c for c in convs if sel(c)]
+            fl = sum(2.0 * c[0] * c[1] * c[2] for c in rows)
+            by = sum((c[4] + c[0] * c[2] + c[1] * c[2]) * 2 for c in rows)
             bound = "mfma" if fl / max(by, 1) * HBM_PEAK_GBS * 1e9 > peak * 1e12 else "hbm"
             return dict(bound=bound, flops=fl, bytes=by, unit_peak=peak, peak_note=note, scope="%d launches per step: %s" % (len(rows), scope))
 
-        if convs or hybrid:
-            work["conv2d_fwd"] = conv_entry(lambda c: True, "implicit-GEMM forward of the BEV / view-transform / LSS-FPN convolutions (csrc/conv2d.hip)")
-            work["conv2d_dgrad"] = conv_entry(lambda c: c[3], "weight transpose + implicit GEMM in transposed-gather mode")
+        if convs:
+            work["conv2d_fwd"] = conv_entry(lambda c: c[5], "implicit-GEMM / pointwise forward of the BEV, view-transform, LSS-FPN and ResNet-50 1x1 "
+                                            "convolutions (csrc/conv2d.hip)")
+            work["conv2d_dgrad"] = conv_entry(lambda c: c[3] and c[6], "weight transpose + implicit GEMM in transposed-gather mode / pointwise GEMM over dy")
             work["conv2d_wgrad"] = conv_entry(lambda c: True, "pixel-major LDS tiles, transposing LDS reads, split pixel range + fixed-order slab sum "
-                                              "(incl. the %d ResNet-50 layers whose forward / data gradient stay on the library)" % len(hybrid), extra=hybrid)
+                                              "(incl. the %d ResNet-50 layers whose forward stays on the library)" % len(hybrid))
         if bns:
             # forward: statistics pass (unless the producing conv accumulated them) + apply (read, write) [+ residual read];
             # backward: reduce (dy, x) + apply (dy, x -> dx) [+ y read and d_residual write for residual layers]

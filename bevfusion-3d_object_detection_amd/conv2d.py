@@ -26,7 +26,6 @@ MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))  # tiny maps
 # layers with fewer input channels stay on the library: the one such layer of the model (dtransform 8 -> 32, 5x5 stride 4 on the
 # 256 x 704 depth images) has an 8-column data gradient over 4.3 M rows -- 0.30 ms on 64-column tiles; 33.43 vs 33.70 ms per step
 MIN_CIN = int(os.environ.get("BFHIP_CONV2D_MIN_CIN", "16"))
-HYBRID_HIP_DGRAD = os.environ.get("BFHIP_HYBRID_HIP_DGRAD", "0") == "1"  # Conv2dHipWgrad: data gradient on the HIP kernel too  # tiny maps: the library's small-problem kernels win
 _WS = {}
 
 # Weight gradients on their own HIP stream (opt-in, BFHIP_WGRAD_SIDE_STREAM=1; bench.py switches it on and joins after the
@@ -125,7 +124,7 @@ def _weight_ohwi(w):
 
 class _Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, emit_stats):
+    def forward(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib=False):
         ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the (non-differentiable) statistics output
         x = _as_nhwc_bf16(x)
         N, Cin, H, W = x.shape
@@ -145,6 +144,7 @@ class _Conv2dFunction(torch.autograd.Function):
                   Cout, KH, KW, stride, pad, dil, 0, _lib.ptr(partial), _lib.stream_of(x))
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, pad, dil)
+        ctx.dgrad_lib = dgrad_lib
         ctx.bias_dtype = bias.dtype if bias is not None else None
         if partial is not None:
             ctx.mark_non_differentiable(partial)
@@ -154,7 +154,7 @@ class _Conv2dFunction(torch.autograd.Function):
     def backward(ctx, dy, _dpartial):
         x, weight = ctx.saved_tensors
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         stride, pad, dil = ctx.geom
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = weight.shape
@@ -164,10 +164,7 @@ class _Conv2dFunction(torch.autograd.Function):
         lib = _lib.load()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
-            ws = _workspace(x.device, lib.bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), stream)
-            _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
-                      W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
+            dx = _lib_dgrad(dy, x, weight, stride, pad, dil) if ctx.dgrad_lib else _hip_dgrad(dy, x, weight, stride, pad, dil)
         side = None
         if ctx.needs_input_grad[1]:
             dw, side = _launch_wgrad(x, dy, weight, stride, pad, dil)
@@ -177,7 +174,24 @@ class _Conv2dFunction(torch.autograd.Function):
                     db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
             else:
                 db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
+
+
+def _hip_dgrad(dy, x, weight, stride, pad, dil):
+    N, Cin, H, W = x.shape
+    Cout, _, KH, KW = weight.shape
+    stream = _lib.stream_of(x)
+    dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    ws = _workspace(x.device, _lib.load().bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), stream)
+    _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
+              W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
+    return dx
+
+
+def _lib_dgrad(dy, x, weight, stride, pad, dil):
+    w = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+    return torch.ops.aten.convolution_backward(dy, x, w, None, [stride] * 2, [pad] * 2, [dil] * 2, False, [0, 0], 1,
+                                               [True, False, False])[0]
 
 
 class _LibConvHipWgradFunction(torch.autograd.Function):
@@ -186,13 +200,14 @@ class _LibConvHipWgradFunction(torch.autograd.Function):
     fp32 zero-fill and a cast launch per call (atomic split-K) and is no faster than the HIP one."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dil):
+    def forward(ctx, x, weight, stride, pad, dil, dgrad_hip=False):
         x = _as_nhwc_bf16(x)
         w = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
         with torch.autocast("cuda", enabled=False):
             y = F.conv2d(x, w, None, stride, pad, dil)
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, pad, dil)
+        ctx.dgrad_hip = dgrad_hip
         return y
 
     @staticmethod
@@ -205,13 +220,10 @@ class _LibConvHipWgradFunction(torch.autograd.Function):
         OH, OW = dy.shape[2], dy.shape[3]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            # (the HIP data gradient here instead was measured: + 0.4 ms per step on the ResNet-50 trunk)
-            w = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride] * 2, [pad] * 2, [dil] * 2, False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            dx = _hip_dgrad(dy, x, weight, stride, pad, dil) if ctx.dgrad_hip else _lib_dgrad(dy, x, weight, stride, pad, dil)
         if ctx.needs_input_grad[1]:
             dw, _ = _launch_wgrad(x, dy, weight, stride, pad, dil)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def _one(v):
@@ -220,9 +232,9 @@ def _one(v):
     return v
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, emit_stats=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, emit_stats=False, dgrad_lib=False):
     """y = conv2d(x, weight, bias) on the HIP path (bf16, channels-last); returns (y, stat_partial | None)."""
-    return _Conv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats))
+    return _Conv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats), bool(dgrad_lib))
 
 
 class Conv2d(nn.Conv2d):
@@ -258,10 +270,21 @@ class Conv2d(nn.Conv2d):
 
 
 class Conv2dHipWgrad(Conv2d):
-    """nn.Conv2d (bias-free) whose forward and data gradient stay on the library and whose weight gradient runs on
-    csrc/conv2d.hip (see _LibConvHipWgradFunction); falls back to nn.Conv2d when the call is not one the HIP kernel serves."""
+    """nn.Conv2d (bias-free) whose weight gradient always runs on csrc/conv2d.hip and whose forward / data gradient take the
+    library (MIOpen / CK through torch) or the HIP kernel, each on its own (`fwd`, `dgrad`: "lib" | "hip"; default: both on the
+    library): for layers where one side's kernel is ahead in one direction only (dense_modules.ResNet50).  A HIP forward
+    emits the BatchNorm statistics like `Conv2d`.  Falls back to nn.Conv2d when the call is not one the HIP kernels serve."""
+
+    fwd = "lib"
+    dgrad = "lib"
 
     def forward(self, x):
         if self.bias is not None or not self.training or not self.hip_eligible(x):
             return nn.Conv2d.forward(self, x)
-        return _LibConvHipWgradFunction.apply(x, self.weight, _one(self.stride), _one(self.padding), _one(self.dilation))
+        s, p, d = _one(self.stride), _one(self.padding), _one(self.dilation)
+        if self.fwd == "hip":
+            y, partial = conv2d(x, self.weight, None, s, p, d, torch.is_grad_enabled(), self.dgrad != "hip")
+            if partial is not None:
+                y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
+            return y
+        return _LibConvHipWgradFunction.apply(x, self.weight, s, p, d, self.dgrad == "hip")

@@ -384,6 +384,85 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
     igemm_epilogue<WGM, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, M, g.Kout, g.ldy, bias, y, stat_partial);
 }
 
+// ------------------------------------------------------------------------------------------------ pointwise (1x1, stride 1)
+// y[m][co] = sum_ci x[m][ci] * Wt[co][ci]: a plain GEMM over a tall activation matrix with a short K (64 ... 256 in the
+// ResNet-50 trunk's bottlenecks, where M = 270 k rows): one to four K steps per tile, so a ring of stages has nothing to
+// overlap inside a workgroup and the layer is bound by HBM, not by the matrix cores.  What hides the latency here is
+// residency: ONE stage of one K step (32 KB for a 128 x 128 tile), at most 128 registers, four to five workgroups per CU
+// at different points of load -> MFMA -> epilogue; no tap table, no divisions (row m IS pixel m).  Same tile, LDS image,
+// swizzle and epilogue (BatchNorm statistics, LDS transpose, 16-byte stores) as conv_igemm_kernel<2, 2, 2, NI>.
+// DIR (0 forward, 1 data gradient) only names the instantiation, so that a kernel trace tells the two uses apart.
+template <int NI, bool OUT_F32, int DIR>
+__global__ __launch_bounds__(256, 4) void conv_pw_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt,
+                                                         const float *__restrict__ bias, void *__restrict__ y,
+                                                         float *__restrict__ stat_partial, long long M, int C, int ldx, int Kout,
+                                                         int ldw, int ldy, int tiles_m, int tiles_n) {
+  constexpr int WGN = 2, MI = 2;
+  constexpr int BM = 128, BN = NI * 64;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int NA = 4, NB = BN / 32;  // DMA instructions per wave and K step (8 rows of 128 bytes each)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles_m * tiles_n);
+  const int tn = (int)(lb % tiles_n), tm = (int)(lb / tiles_n);
+  const long long m0 = (long long)tm * BM;
+  const int n0 = tn * BN;
+  const int nq = C >> 3, nt = (nq + 7) >> 3;
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const bf16_t *zsrc = zero_src();
+  const bf16_t *arow[NA], *brow[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const long long m = m0 + w * 32 + i * 8 + lrow;
+    arow[i] = m < M ? x + (unsigned)m * (unsigned)ldx : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int co = n0 + w * (NB * 8) + i * 8 + lrow;
+    brow[i] = co < Kout ? wt + (size_t)co * ldw : nullptr;
+  }
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  const int wm = w / WGN, wn = w % WGN;
+  const int l31 = lane & 31, lh = lane >> 5, rswz = (lane >> 1) & 7;
+  const unsigned char *pA = smem + (wm * 64 + l31) * 128, *pB = smem + A_BYTES + (wn * (NI * 32) + l31) * 128;
+  unsigned char *dA = smem + (w * 32) * 128, *dB = smem + A_BYTES + (w * (NB * 8)) * 128;
+  for (int t = 0; t < nt; ++t) {
+    if (t) __syncthreads();  // every wave has consumed the previous K step
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = t * 8 + (lpos ^ (((w * 32 + i * 8 + lrow) >> 1) & 7));
+      glds16(arow[i] && q < nq ? arow[i] + q * 8 : zsrc, dA + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = t * 8 + (lpos ^ (((w * (NB * 8) + i * 8 + lrow) >> 1) & 7));
+      glds16(brow[i] && q < nq ? brow[i] + q * 8 : zsrc, dB + i * 1024);
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int pos = ((2 * ks + lh) ^ rswz) << 4;
+      bf16x8 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8 *)(pA + mi * 32 * 128 + pos);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8 *)(pB + ni * 32 * 128 + pos);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  igemm_epilogue<2, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, M, Kout, ldy, bias, y, stat_partial);
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[co][k] = sum over pixels of dy[m][co] * A[m][k].  LDS tiles are pixel-major: dy [64][128 co], A [64][128 k]
 // (256-byte rows; piece c of row r at position c ^ (((r & 3) << 2) | ((r >> 2) & 3)), conflict-free for the
@@ -992,6 +1071,32 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
   // BFHIP_CONV_TILE256: 0 = never, 1 = by the rule below, 2 = whenever the output is bf16 and wider than 128 (tests)
   static const int tile256 = [] { const char *e = getenv("BFHIP_CONV_TILE256"); return e ? atoi(e) : 1; }();
   static const int tile256_min = [] { const char *e = getenv("BFHIP_CONV_TILE256_MIN"); return e ? atoi(e) : 384; }();
+  // 1x1, stride 1, no padding (forward, or the data gradient of such a layer: both are plain GEMMs over the pixel matrix)
+  // with a short K: conv_pw_kernel.  BFHIP_CONV_PW_MAXC: largest channel count of the gathered tensor it takes (0 = never)
+  static const int pw_maxc = [] { const char *e = getenv("BFHIP_CONV_PW_MAXC"); return e ? atoi(e) : 4096; }();
+  if (g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0 && g.transposed != 2 && g.C <= pw_maxc) {
+    const int ni = g.Kout > 64 ? 2 : 1, BN = ni * 64;
+    const int tiles_m = ceil_div(g.M, 128), tiles_n = ceil_div(g.Kout, BN);
+    const size_t stage = (size_t)(128 + BN) * 128, epi = (size_t)128 * BN * (out_f32 ? 4 : 2);
+    const size_t lds = stage > epi ? stage : epi;
+    dim3 grid((unsigned)((long long)tiles_m * tiles_n));
+#define BFHIP_PW(NIV, F32, DIRV)                                                                                        \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void *)conv_pw_kernel<NIV, F32, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_pw_kernel<NIV, F32, DIRV>), grid, dim3(256), lds, s, (const bf16_t *)x, (const bf16_t *)wt, bias, y, \
+                       stat_partial, g.M, g.C, g.ldx, g.Kout, g.ldw, g.ldy, tiles_m, tiles_n);                         \
+  } while (0)
+#define BFHIP_PW2(NIV, F32) do { if (g.transposed) BFHIP_PW(NIV, F32, 1); else BFHIP_PW(NIV, F32, 0); } while (0)
+    if (ni == 2) { if (out_f32) BFHIP_PW2(2, true); else BFHIP_PW2(2, false); }
+    else { if (out_f32) BFHIP_PW2(1, true); else BFHIP_PW2(1, false); }
+#undef BFHIP_PW2
+#undef BFHIP_PW
+    return check_launch(what);
+  }
   int shape = g.Kout > 64 ? 1 : 0;
   const long long t256 = (long long)ceil_div(g.M, 256) * ceil_div(g.Kout, 256);
   // enough tiles for the 256 one-workgroup CUs, and at most 1/8 of the 256-wide column tiles wasted

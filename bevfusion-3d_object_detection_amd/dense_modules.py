@@ -30,21 +30,39 @@ from .registry import MODELS
 
 
 # ----------------------------------------------------------------------------- image backbone
-# Which parts of the ResNet-50 trunk's convolutions take csrc/conv2d.hip (BFHIP_RESNET_CONV): "hipwgrad" (default) = the
-# weight gradients only, forward and data gradient stay on MIOpen / CK through torch (conv2d.Conv2dHipWgrad): 34.28 / 34.30 ms
-# per `full` step against 34.61 / 34.61 ms for "lib" on the same box -- the library's weight gradient brings an fp32 zero-fill and
-# a cast launch per call and is no faster than the HIP one; "lib" = nothing; "hip3x3" = the sixteen 3x3 convolutions entirely;
-# "hip" = the 1x1 ones as well.  (The 7x7 stem has 3 input channels and always stays on the library.)  Measured on one box, ms
-# per `full` step: lib 34.84 / 34.51, hip3x3 34.65, hip 35.28 -- the
-# 3x3 layers are a wash (the HIP kernels save the BatchNorm statistics pass and MIOpen's zero-fill / cast helpers and lose
-# 10-25 % in the forward), the 1x1 layers (K = 64 ... 512: one to eight K steps per tile, HBM-bound) run at half the library's
-# rate in the forward.  Routing them through F.linear (hipBLASLt) instead was also measured: 41.3 ms (its weight-gradient GEMMs
-# over 270 k-row operands are slow).  "hip3x3+hipwgrad" (HIP 3x3 entirely, hybrid 1x1): 34.0-34.3 vs 33.7-33.8 ms for "hipwgrad".
-_RESNET_CONV = os.environ.get("BFHIP_RESNET_CONV", "hipwgrad")
+# Which kernels the ResNet-50 trunk's 52 convolutions take (BFHIP_RESNET_CONV).  The weight gradient is csrc/conv2d.hip's in
+# every mode but "lib" (the library's brings an fp32 zero-fill and a cast launch per call and is no faster).  Forward and data
+# gradient, GPU time per call from `tools/resnet_conv_micro.py` (graph replay, batch 24 x 64 x 176 after the stem; sums over the
+# trunk): library forward 1.72 ms, HIP 1.96 ms -- but a HIP forward hands the BatchNorm behind it its statistics (0.34 ms of
+# statistics passes over the trunk); library data gradient 2.52 ms (with its zero-fill of dx), HIP 2.49 ms, where the HIP side
+# wins every stride-1 layer (1x1: conv_pw_kernel, 20-35 % ahead; 3x3 up to 256 channels: 10-25 % ahead) and loses every stride-2
+# one by 1.5-2.3x (the 1x1 stride-2 shortcuts write three zero pixels out of four through the full tile machinery).  Hence
+#   "tuned" (default): 1x1 stride 1 -> HIP forward + HIP data gradient; 3x3 stride 1 -> library forward, HIP data gradient up to
+#                      256 channels; stride 2 (three 3x3, three shortcuts) -> library both ways
+#   "hipwgrad": library forward and data gradient everywhere (round 2's default); "lib": the library for everything;
+#   "hip3x3" / "hip" / "hip3x3+hipwgrad": the 3x3 / all / 3x3-only layers entirely on the HIP kernels (round-2 experiments:
+#   34.65 / 35.28 / 34.0-34.3 ms per `full` step against 33.7-33.8 for "hipwgrad")
+# (The 7x7 stem has 3 input channels and always stays on the library.)
+_RESNET_CONV = os.environ.get("BFHIP_RESNET_CONV", "tuned")
 
 
-_Conv3x3 = Conv2d if _RESNET_CONV in ("hip", "hip3x3", "hip3x3+hipwgrad") else (Conv2dHipWgrad if _RESNET_CONV == "hipwgrad" else nn.Conv2d)
-_Conv1x1 = Conv2d if _RESNET_CONV == "hip" else (Conv2dHipWgrad if _RESNET_CONV in ("hipwgrad", "hip3x3+hipwgrad") else nn.Conv2d)
+def _resnet_conv(cin, cout, k, stride=1, padding=0, bias=False):
+    mode = _RESNET_CONV
+    if mode == "tuned":
+        m = Conv2dHipWgrad(cin, cout, k, stride=stride, padding=padding, bias=bias)
+        if stride == 1 and k == 1:
+            m.fwd = m.dgrad = "hip"
+        elif stride == 1 and cin <= 256:
+            m.dgrad = "hip"
+        return m
+    if k == 1:
+        cls = Conv2d if mode == "hip" else (Conv2dHipWgrad if mode in ("hipwgrad", "hip3x3+hipwgrad") else nn.Conv2d)
+    else:
+        cls = Conv2d if mode in ("hip", "hip3x3", "hip3x3+hipwgrad") else (Conv2dHipWgrad if mode == "hipwgrad" else nn.Conv2d)
+    return cls(cin, cout, k, stride=stride, padding=padding, bias=bias)
+
+
+_Conv3x3 = _Conv1x1 = _resnet_conv
 
 
 class _Bottleneck(nn.Module):

@@ -34,7 +34,12 @@ GEOMS = [(2, 45, 52, 336, 256, 3, 1, 1, 1, False),   # ConvFuser (BF/bevfusion_h
          (1, 17, 19, 16, 16, 5, 4, 2, 1, True),      # 5x5 stride 4 on odd extents: classes with 1, 2 and 4 taps
          (2, 132, 128, 16, 256, 3, 1, 1, 1, False),  # 528 tiles of 128 x 128 = 1.03 residency rounds: forward switches to 128 x 64 tiles
          (2, 223, 225, 16, 256, 3, 1, 1, 1, True),   # >= 384 row tiles x 256 columns: forward takes the 256 x 256 tile kernel
-         (2, 223, 225, 256, 16, 3, 1, 1, 1, False)]  # ... and here the data gradient does (its GEMM columns are Cin = 256)
+         (2, 223, 225, 256, 16, 3, 1, 1, 1, False),  # ... and here the data gradient does (its GEMM columns are Cin = 256)
+         # pointwise kernel (conv_pw_kernel: 1x1, stride 1, <= 128 gathered channels)
+         (3, 33, 47, 64, 256, 1, 1, 0, 1, False),    # ResNet bottleneck expand: forward pointwise (one K step), dgrad implicit GEMM
+         (3, 33, 47, 256, 64, 1, 1, 0, 1, False),    # ResNet bottleneck reduce: dgrad pointwise over dy (64 channels)
+         (2, 33, 47, 72, 40, 1, 1, 0, 1, True),      # 64-column tile, K = 72 (a partial second K step), bias, partial column tile
+         (2, 31, 29, 128, 136, 1, 1, 0, 1, False)]   # two K steps, second column tile 8 wide, rows not a multiple of 128
 
 
 def _bf16_round(a):
@@ -92,9 +97,11 @@ def test_forward_backward_vs_torch_cpu(dev, g):
                                (3, 32, 88, 128, 128, 3, 2, 1, 1, False),    # ResNet 3x3 stride 2
                                (2, 44, 52, 256, 64, 1, 1, 0, 1, False)],    # 1x1 reduce
                          ids=lambda g: "x".join(str(v) for v in g[:9]))
-def test_library_forward_hip_wgrad_hybrid(dev, g):
-    """Conv2dHipWgrad (the ResNet-50 trunk's convolutions): forward and data gradient by the library, weight gradient by
-    csrc/conv2d.hip; same tolerances as the all-HIP path against torch on the CPU in fp32."""
+@pytest.mark.parametrize("fwd,dgrad", [("lib", "lib"), ("lib", "hip"), ("hip", "hip"), ("hip", "lib")])
+def test_library_forward_hip_wgrad_hybrid(dev, g, fwd, dgrad):
+    """Conv2dHipWgrad (the ResNet-50 trunk's convolutions): weight gradient by csrc/conv2d.hip, forward and data gradient each
+    by the library or the HIP kernel (dense_modules picks per layer); same tolerances as the all-HIP path against torch on the
+    CPU in fp32.  A HIP forward must also hand over its BatchNorm statistics."""
     from bevfusion_amd.conv2d import Conv2dHipWgrad
     N, H, W, Cin, Cout, k, s, p, d, _ = g
     x, w, _ = _case(g, seed=sum(g[:9]))
@@ -103,6 +110,7 @@ def test_library_forward_hip_wgrad_hybrid(dev, g):
     gy = _bf16_round(np.random.default_rng(9).standard_normal(tuple(ref.shape)).astype(np.float32))
     ref.backward(gy)
     conv = Conv2dHipWgrad(Cin, Cout, k, stride=s, padding=p, dilation=d, bias=False).to(dev).train()
+    conv.fwd, conv.dgrad = fwd, dgrad
     with torch.no_grad():
         conv.weight.copy_(w)
     conv.to(memory_format=torch.channels_last)
@@ -110,6 +118,11 @@ def test_library_forward_hip_wgrad_hybrid(dev, g):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = conv(xg)
     assert y.dtype == torch.bfloat16 and _rel(y.float().cpu(), ref.detach()) < 1e-2
+    part = getattr(y, "_bfhip_stat_partial", None)
+    assert (part is not None) == (fwd == "hip")
+    if part is not None:
+        r = ref.detach().double()
+        assert torch.allclose(part[0][:, 0].double().sum(0).cpu(), r.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * float(r.abs().max()))
     y.backward(gy.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
     assert _rel(xg.grad.float().cpu(), xr.grad) < 1e-2 and _l2(xg.grad.float().cpu(), xr.grad) < 4e-3
     assert conv.weight.grad.dtype == torch.float32 and _rel(conv.weight.grad.cpu(), wr.grad) < 1e-4
@@ -119,11 +132,13 @@ def test_library_forward_hip_wgrad_hybrid(dev, g):
         assert _rel(conv(xg).float().cpu(), ref.detach()) < 1e-2
 
 
-def test_fp32_output_is_exact_on_integer_data(dev):
+@pytest.mark.parametrize("geom", [(40, 72, 3, 2, 1), (72, 136, 1, 1, 0), (128, 40, 1, 1, 0)], ids=["3x3s2", "pointwise_72_136", "pointwise_128_40"])
+def test_fp32_output_is_exact_on_integer_data(dev, geom):
     """Integer-valued operands: every product and partial sum is exact in fp32, so the fp32-output forward / dgrad and the
     weight gradient must equal torch's CPU result bit for bit -- whatever the summation order.  Catches any misplaced
-    tap, row or swizzle that a tolerance could hide."""
-    N, H, W, Cin, Cout, k, s, p, d = 2, 19, 23, 40, 72, 3, 2, 1, 1
+    tap, row or swizzle that a tolerance could hide.  (The two 1x1 cases run conv_pw_kernel with fp32 output, both tile widths.)"""
+    N, H, W, d = 2, 19, 23, 1
+    Cin, Cout, k, s, p = geom
     rng = np.random.default_rng(3)
     x = torch.from_numpy(rng.integers(-3, 4, (N, Cin, H, W)).astype(np.float32))
     w = torch.from_numpy(rng.integers(-2, 3, (Cout, Cin, k, k)).astype(np.float32))

@@ -20,8 +20,8 @@ FAMILIES = [
     ("bn2d forward (stats, finalize, apply)", lambda n: "bn2d_" in n),
     # last template argument of conv_igemm_kernel = MODE: 0 forward, 1 data gradient (transposed gather), 2 data gradient of a
     # strided layer by parity classes (round 2 matched a bool that no longer exists and booked these under the forward)
-    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*, [12]>", n) is not None),
-    ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n),
+    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*, [12]>|conv_pw_kernel<[^>]*, 1>", n) is not None),
+    ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n or "conv_pw_kernel" in n),
     ("conv2d wgrad (main kernel)", lambda n: "conv_wgrad_kernel" in n or "conv_wgrad_wide_kernel" in n),
     ("conv weight transpose", lambda n: "conv_weight_transpose" in n),
     ("bn1d", lambda n: "bn1d_" in n),
