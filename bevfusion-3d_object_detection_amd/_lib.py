@@ -85,6 +85,8 @@ SIGNATURES = {
                        [_c_vp, _c_sz, _c_vp]),
     "bfhip_attn_dropout_mask": (_c_int, [_c_int] * 4 + [ctypes.c_float, ctypes.c_ulonglong, _c_vp, _c_vp, _c_vp]),
     "bfhip_upsample2x_nhwc": (_c_int, [_c_vp, _c_vp] + [_c_int] * 6 + [_c_vp]),
+    "bfhip_maxpool3x3s2_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp, _c_vp, _c_vp]),
+    "bfhip_maxpool3x3s2_bwd": (_c_int, [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp, _c_vp]),
     "bfhip_circle_nms": (_c_int, [_c_vp, _c_int, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp]),
     "bfhip_rotate_nms_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "bfhip_rotate_nms": (_c_int, [_c_vp, _c_vp, _c_int, ctypes.c_float, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
@@ -101,6 +103,9 @@ SIGNATURES = {
     "bfhip_conv2d_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp, _c_vp]),
     "bfhip_conv2d_dgrad_workspace_bytes": (_c_sz, [_c_int] * 4),
     "bfhip_conv2d_dgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_conv2d_dgrad_wt": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp]),
+    "bfhip_conv2d_wt_segment_bytes": (_c_int, []),
+    "bfhip_conv2d_weight_transpose_batched": (_c_int, [_c_vp, _c_int, ctypes.c_longlong, _c_vp]),
     "bfhip_conv2d_wgrad_workspace_bytes": (_c_sz, [_c_int] * 7),
     "bfhip_conv2d_wgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_bn2d_fwd_partials": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +

@@ -74,6 +74,12 @@ class MasterWeightAdamW:
             self._steps = list(self._steps_flat.unbind(0))  # 0-d views: one add_ on the flat tensor advances them all
             g = self.opt.param_groups[0]
             self._hyper = dict(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], weight_decay=g["weight_decay"], eps=g["eps"])
+        # transposed bf16 copies of the conv weights for the HIP data gradients, all layers in one launch after every update
+        # (conv2d.TransposedWeights); built last: the parameters have their final storage now.  BFHIP_WT_CACHE=0: per-call transposes
+        self.transposed = None
+        if os.environ.get("BFHIP_WT_CACHE", "1") == "1" and all(p.is_cuda for p in self.master + self.other):
+            from .conv2d import TransposedWeights
+            self.transposed = TransposedWeights(model.modules())
 
     # ------------------------------------------------------------------ flat path
     def _build_flat(self, lr, weight_decay):
@@ -146,6 +152,11 @@ class MasterWeightAdamW:
 
     @torch.no_grad()
     def step(self):
+        self._update()
+        if self.transposed is not None:
+            self.transposed.refresh()
+
+    def _update(self):
         if self.flat:
             return self._step_flat()
         have = [(m.grad, p.grad) for m, p in zip(self.master, self.low) if p.grad is not None]

@@ -182,6 +182,11 @@ def _hip_dgrad(dy, x, weight, stride, pad, dil):
     Cout, _, KH, KW = weight.shape
     stream = _lib.stream_of(x)
     dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    cached = getattr(weight, "_bfhip_wt", None)  # TransposedWeights: (wt, weight._version, weight.data_ptr()) at refresh time
+    if cached is not None and cached[1] == weight._version and cached[2] == weight.data_ptr():
+        _lib.call("bfhip_conv2d_dgrad_wt", dy.data_ptr(), _nhwc_view(dy), cached[0].data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin,
+                  Cout, KH, KW, stride, pad, dil, 0, stream)
+        return dx
     ws = _workspace(x.device, _lib.load().bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), stream)
     _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
               W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
@@ -224,6 +229,59 @@ class _LibConvHipWgradFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw, _ = _launch_wgrad(x, dy, weight, stride, pad, dil)
         return dx, dw, None, None, None, None
+
+
+class TransposedWeights:
+    """bf16 [Cin][KH][KW][Cout] copies of the weights of every convolution whose data gradient runs on csrc/conv2d.hip,
+    refreshed for ALL layers in one launch (`refresh()`: after the optimizer step).  Without it every data gradient starts with
+    its own transpose launch (~5 us, 69 per `full` step).  A copy rides on its parameter (`weight._bfhip_wt`) with the
+    parameter's version counter and address at refresh time; `_hip_dgrad` uses it only while both still match, so a weight
+    edited through torch since (load_state_dict, an in-place op) falls back to the per-call transpose until the next refresh.
+    Kernels that write parameters behind torch's back (amp.MasterWeightAdamW's one-table update) must call `refresh()` after."""
+
+    def __init__(self, modules):
+        import numpy as np
+        self.items = []
+        recs = []
+        blk = 0
+        seg_bytes = _lib.load().bfhip_conv2d_wt_segment_bytes()
+        assert seg_bytes == 40, seg_bytes
+        for m in modules:
+            if not isinstance(m, Conv2d) or m.groups != 1 or not m.weight.is_cuda:
+                continue
+            if isinstance(m, Conv2dHipWgrad) and m.dgrad != "hip":
+                continue
+            w = m.weight
+            if w.dtype not in (torch.bfloat16, torch.float32) or not w.permute(0, 2, 3, 1).is_contiguous():
+                continue
+            Cout, Cin, KH, KW = w.shape
+            wt = torch.empty(Cin * KH * KW * Cout, dtype=torch.bfloat16, device=w.device)
+            self.items.append((w, wt))
+            recs.append((w.data_ptr(), wt.data_ptr(), Cout, KH * KW, Cin, 1 if w.dtype == torch.float32 else 0, blk))
+            blk += -(-Cin // 32) * -(-Cout // 32) * KH * KW
+        self.blocks = blk
+        self.table = None
+        if recs:
+            dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"), ("f32", "<i4"), ("blk0", "<i8")])
+            arr = np.array(recs, dtype=dt)
+            self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.items[0][0].device)
+            self._ptrs = [r[0] for r in recs]
+        self.refresh()
+
+    def refresh(self):
+        if self.table is None:
+            return
+        # a parameter whose storage moved (``.to()``, ``.data = ...``) invalidates the table: drop its copy instead of reading a
+        # stale address
+        if any(w.data_ptr() != p for (w, _), p in zip(self.items, self._ptrs)):
+            for w, _ in self.items:
+                w._bfhip_wt = None
+            self.table = None
+            return
+        _lib.call("bfhip_conv2d_weight_transpose_batched", self.table.data_ptr(), len(self.items), self.blocks,
+                  _lib.stream_of(self.table))
+        for w, wt in self.items:
+            w._bfhip_wt = (wt, w._version, w.data_ptr())
 
 
 def _one(v):

@@ -246,41 +246,52 @@ __global__ __launch_bounds__(256) void bn2d_stats_kernel(const T *__restrict__ x
   finish_in_last_block(partial, tr, C, blockIdx.y * mp.Lb * V, mp.Lb * V, fin);
 }
 
-// 8 channels per block x 32 slab lanes; every lane issues its (<= 32) loads in independent groups of 4, then a fixed-order
-// fp64 combine through LDS.  The serial chain per launch is ~8 L2 round trips whatever the number of slabs.
+// 8 channels per block x 64 slab lanes (512 threads); a lane issues ALL of its loads (<= 16 for up to 1024 slabs) before the
+// first add, then a fixed-order fp64 combine through LDS in two levels (8 x 8 lanes, then 8).  The kernel is pure latency --
+// a few KB of partial sums per channel -- and runs 208 times per training step: with round 2's groups of 4 loads its serial
+// chain was ~8 L2 round trips (6.4 us per launch); now it is one round trip, two barriers and the per-channel arithmetic.
+constexpr int kFinLanes = 64, kFinThreads = 8 * kFinLanes;
 __device__ __forceinline__ void reduce_partials8(const float *__restrict__ partial, int nblk, int C, int c, bool ok,
                                                  double &s, double &s2) {
-  __shared__ double sm[2][256];
-  const int kl = threadIdx.x >> 3;  // 0..31
+  __shared__ double sm[2][kFinThreads];
+  const int t = threadIdx.x, kl = t >> 3;  // slab lane 0..63
   double a = 0.0, b = 0.0;
   if (ok) {
-    int k = kl;
-    for (; k + 96 < nblk; k += 128) {
-      float v0[4], v1[4];
+    for (int k0 = kl; k0 < nblk; k0 += 16 * kFinLanes) {
+      float v0[16], v1[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v0[u] = partial[((size_t)(k + 32 * u) * 2 + 0) * C + c];
-        v1[u] = partial[((size_t)(k + 32 * u) * 2 + 1) * C + c];
+      for (int u = 0; u < 16; ++u) {
+        // unconditional loads from a clamped row (a predicated load is a branch the compiler will not issue loads across)
+        const int k = k0 + u * kFinLanes, kc = k < nblk ? k : nblk - 1;
+        v0[u] = partial[((size_t)kc * 2 + 0) * C + c];
+        v1[u] = partial[((size_t)kc * 2 + 1) * C + c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a += (double)v0[u]; b += (double)v1[u]; }
-    }
-    for (; k < nblk; k += 32) {
-      a += (double)partial[((size_t)k * 2 + 0) * C + c];
-      b += (double)partial[((size_t)k * 2 + 1) * C + c];
+      for (int u = 0; u < 16; ++u)
+        if (k0 + u * kFinLanes < nblk) { a += (double)v0[u]; b += (double)v1[u]; }
     }
   }
-  sm[0][threadIdx.x] = a;
-  sm[1][threadIdx.x] = b;
+  sm[0][t] = a;
+  sm[1][t] = b;
+  __syncthreads();
+  double x = 0.0, y = 0.0;
+  if (t < 64) {  // channel t & 7, lanes 8 * (t >> 3) ... + 7
+    const int ch = t & 7, g = t >> 3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x += sm[0][(g * 8 + j) * 8 + ch]; y += sm[1][(g * 8 + j) * 8 + ch]; }
+  }
+  __syncthreads();
+  if (t < 64) { sm[0][t] = x; sm[1][t] = y; }
   __syncthreads();
   s = 0.0; s2 = 0.0;
-  if (threadIdx.x < 8)
-    for (int k = 0; k < 32; ++k) { s += sm[0][k * 8 + threadIdx.x]; s2 += sm[1][k * 8 + threadIdx.x]; }
+  if (t < 8)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { s += sm[0][g * 8 + t]; s2 += sm[1][g * 8 + t]; }
 }
 
 // finalisation as its own launch: for partial sums that come from somewhere else (the conv epilogue, bfhip_bn2d_fwd_partials)
 template <typename Fin>
-__global__ __launch_bounds__(256) void bn2d_finalize_kernel(const float *__restrict__ partial, int nblk, Fin fin) {
+__global__ __launch_bounds__(kFinThreads) void bn2d_finalize_kernel(const float *__restrict__ partial, int nblk, Fin fin) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double s, s2;
   reduce_partials8(partial, nblk, fin.C, c, c < fin.C, s, s2);
@@ -500,7 +511,7 @@ void run_bwd(const void *dy, const void *x, const void *y, const float *stats, l
              float *partial, float *coef, Tree tr, BwdFin fin, void *dx, void *dres, hipStream_t s) {
   hipLaunchKernelGGL((bn2d_bwd_reduce_kernel<T, MASK>), grid, dim3(256), 0, s, (const T *)dy, (const T *)x,
                      (const T *)y, stats, M, C, mp, partial, tr, fin);
-  if (!tr.cnt) hipLaunchKernelGGL(bn2d_finalize_kernel<BwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, tr.nblk, fin);
+  if (!tr.cnt) hipLaunchKernelGGL(bn2d_finalize_kernel<BwdFin>, dim3(ceil_div(C, 8)), dim3(kFinThreads), 0, s, partial, tr.nblk, fin);
   if (dres)
     hipLaunchKernelGGL((bn2d_bwd_apply_kernel<T, MASK, true>), grid, dim3(256), 0, s, (const T *)dy, (const T *)x,
                        (const T *)y, stats, coef, M, C, mp, (T *)dx, (T *)dres);
@@ -605,7 +616,7 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
     hipLaunchKernelGGL(bn2d_stats_kernel<bf16_t>, pl.grid, dim3(256), 0, s, (const bf16_t *)x, M, C, pl.mp, pl.partial, tr, fin);
   else
     hipLaunchKernelGGL(bn2d_stats_kernel<float>, pl.grid, dim3(256), 0, s, (const float *)x, M, C, pl.mp, pl.partial, tr, fin);
-  if (!cnt) hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, pl.partial, pl.nblk, fin);
+  if (!cnt) hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(kFinThreads), 0, s, pl.partial, pl.nblk, fin);
   if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, pl.mp, pl.grid, relu, y, s);
   else run_fwd<float>(x, residual, stats, M, C, pl.mp, pl.grid, relu, y, s);
   prof_end(&ps);
@@ -626,7 +637,7 @@ BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, co
   FwdFin fin{M, m_dev, C, eps, momentum, gamma, beta, stats, running_mean, running_var};
   ProfScope ps;
   prof_begin(BFHIP_OP_BN2D_FWD, s, &ps);
-  hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(256), 0, s, partial, nblk, fin);
+  hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(kFinThreads), 0, s, partial, nblk, fin);
   if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
   else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
   prof_end(&ps);

@@ -983,6 +983,47 @@ __global__ __launch_bounds__(256) void conv_weight_transpose_kernel(const bf16_t
   }
 }
 
+// The same for a table of weights in ONE launch (all layers of a model after the optimizer step: a training step otherwise
+// pays one ~5 us transpose launch per data gradient, 69 per step).  Segment i owns blocks [blk0[i], blk0[i + 1]).
+struct WtSeg {
+  const void *src;   // [Cout][taps][Cin], bf16 or fp32 (src_f32)
+  bf16_t *dst;       // [Cin][taps][Cout]
+  int Cout, taps, Cin, src_f32;
+  long long blk0;
+};
+__global__ __launch_bounds__(256) void conv_weight_transpose_batched_kernel(const WtSeg *__restrict__ segs, int nseg) {
+  __shared__ bf16_t tile[32][33];
+  const long long b = blockIdx.x;
+  int lo = 0, hi = nseg - 1;  // largest segment with blk0 <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const WtSeg sg = segs[lo];
+  const int nx = (sg.Cin + 31) >> 5, ny = (sg.Cout + 31) >> 5;
+  int local = (int)(b - sg.blk0);
+  const int bx = local % nx; local /= nx;
+  const int by = local % ny;
+  const int tap = local / ny;
+  if (tap >= sg.taps) return;
+  const int c0 = bx * 32, o0 = by * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = o0 + r, ci = c0 + tx;
+    bf16_t v = 0;
+    if (co < sg.Cout && ci < sg.Cin) {
+      const size_t i = ((size_t)co * sg.taps + tap) * sg.Cin + ci;
+      v = sg.src_f32 ? (bf16_t)rne_bf16(((const float *)sg.src)[i]) : ((const bf16_t *)sg.src)[i];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = c0 + r, co = o0 + tx;
+    if (ci < sg.Cin && co < sg.Cout) sg.dst[((size_t)ci * sg.taps + tap) * sg.Cout + co] = tile[tx][r];
+  }
+}
+
 // K pieces (16-byte = 8-channel pieces of one tap) a kernel can hold a tap table for: 4 bytes per piece beside 64 KB of
 // stages under the 80 KB dynamic-LDS attribute of the two-workgroups-per-CU tiles (the 256-wide tiles have 31 KB beside
 // 128 KB, the wide weight-gradient tiles 16 KB beside 144 KB).  C is Cin for forward / weight gradient and Cout for the data
@@ -1179,20 +1220,21 @@ BFHIP_EXPORT size_t bfhip_conv2d_dgrad_workspace_bytes(int Cin, int Cout, int KH
 
 // dx[N, H, W, Cin] = conv_transpose(dy[N, OH, OW, Cout], w): the forward kernel in transposed-gather mode over the
 // [Cin][KH][KW][Cout] transpose of the weight (built in `workspace`).
-BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin,
-                                    int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace,
-                                    size_t workspace_bytes, void *stream_) {
-  hipStream_t s = (hipStream_t)stream_;
+// w: the convolution's weight (transposed into `workspace` first) or, with w == nullptr, `workspace` IS the transposed weight
+static int conv2d_dgrad_impl(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin, int Cout,
+                             int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace, size_t workspace_bytes,
+                             hipStream_t s) {
   BFHIP_REQUIRE(bfhip_conv2d_supported(N, H, W, Cin, Cout, KH, KW, stride, pad, dil), "conv2d_dgrad: unsupported geometry");
-  BFHIP_REQUIRE(dy && w && dx && workspace, "conv2d_dgrad: null pointer");
+  BFHIP_REQUIRE(dy && dx && workspace, "conv2d_dgrad: null pointer");
   BFHIP_REQUIRE(workspace_bytes >= bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), "conv2d_dgrad: workspace too small");
   BFHIP_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)workspace % 16) == 0 && ldg % 8 == 0 && ldg >= Cout && ldx >= Cin,
                 "conv2d_dgrad: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
   const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   ProfScope ps;
   prof_begin(BFHIP_OP_CONV2D_DGRAD, s, &ps);
-  hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW), dim3(256), 0, s,
-                     (const bf16_t *)w, (bf16_t *)workspace, Cout, KH * KW, Cin);
+  if (w)
+    hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW), dim3(256), 0, s,
+                       (const bf16_t *)w, (bf16_t *)workspace, Cout, KH * KW, Cin);
   ConvGeom g = {};
   g.N = N; g.H = OH; g.W = OW; g.C = Cout; g.ldx = ldg;   // gathered tensor = dy
   g.OH = H; g.OW = W;                                    // GEMM rows = input pixels
@@ -1227,6 +1269,32 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
   const int rc = launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad");
   prof_end(&ps);
   return rc;
+}
+
+BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace,
+                                    size_t workspace_bytes, void *stream_) {
+  BFHIP_REQUIRE(w, "conv2d_dgrad: null pointer");
+  return conv2d_dgrad_impl(dy, ldg, w, dx, ldx, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, out_f32, workspace, workspace_bytes,
+                           (hipStream_t)stream_);
+}
+
+// the same with the weight already transposed: wt bf16 [Cin][KH][KW][Cout] (bfhip_conv2d_weight_transpose_batched); read-only
+BFHIP_EXPORT int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, void *dx, int ldx, int N, int H, int W, int Cin,
+                                       int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, void *stream_) {
+  return conv2d_dgrad_impl(dy, ldg, nullptr, dx, ldx, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, out_f32, (void *)wt,
+                           bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), (hipStream_t)stream_);
+}
+
+BFHIP_EXPORT int bfhip_conv2d_wt_segment_bytes(void) { return (int)sizeof(WtSeg); }
+
+// segs_dev: nseg device records {u64 src, u64 dst, i32 Cout, i32 taps, i32 Cin, i32 src_f32, i64 first block}, blocks of a
+// segment = ceil(Cin / 32) * ceil(Cout / 32) * taps, first blocks ascending from 0; total_blocks = their sum
+BFHIP_EXPORT int bfhip_conv2d_weight_transpose_batched(const void *segs_dev, int nseg, long long total_blocks, void *stream_) {
+  BFHIP_REQUIRE(segs_dev && nseg > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "conv2d_weight_transpose_batched: bad table");
+  hipLaunchKernelGGL(conv_weight_transpose_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream_,
+                     (const WtSeg *)segs_dev, nseg);
+  return check_launch("conv2d_weight_transpose_batched");
 }
 
 static int resident_blocks() {  // workgroups the chip holds at once (2 per CU: 66 KB of LDS each)

@@ -86,6 +86,47 @@ class _Bottleneck(nn.Module):
         return self.bn3(self.conv3(out), residual=identity, relu=True)  # BN + identity + ReLU in one pass
 
 
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        tap = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+        _lib.call("bfhip_maxpool3x3s2_fwd", x.data_ptr(), N, H, W, C, y.data_ptr(), tap.data_ptr(), _lib.stream_of(x))
+        ctx.save_for_backward(tap)
+        ctx.dims = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tap,) = ctx.saved_tensors
+        N, C, H, W = ctx.dims
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+        _lib.call("bfhip_maxpool3x3s2_bwd", dy.data_ptr(), tap.data_ptr(), N, H, W, C, dx.data_ptr(), _lib.stream_of(dy))
+        return dx
+
+
+class MaxPool3x3s2(nn.MaxPool2d):
+    """nn.MaxPool2d(3, stride=2, padding=1) (the ResNet stem's pooling); a channels-last bf16 CUDA map takes csrc/pool.hip
+    (forward with the winning tap per element, backward as a gather: 0.10 + 0.25 ms -> see DESIGN.md), anything else the
+    library.  `BFHIP_MAXPOOL=0` switches the HIP path off."""
+
+    ENABLED = os.environ.get("BFHIP_MAXPOOL", "1") == "1"
+
+    def __init__(self):
+        super().__init__(3, stride=2, padding=1)
+
+    def forward(self, x):
+        if (self.ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0
+                and x.numel() < (1 << 31) and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0):
+            return _MaxPool3x3s2.apply(x)
+        return super().forward(x)
+
+
 @MODELS.register_module()
 class ResNet50(nn.Module):
     """Standard ResNet-50; returns the stride-8/16/32 maps (512, 1024, 2048 channels)."""
@@ -96,7 +137,7 @@ class ResNet50(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = BatchNorm2dAct(64)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.maxpool = MaxPool3x3s2()
         self.inplanes = 64
         self.layer1 = self._make_layer(64, 3, 1)
         self.layer2 = self._make_layer(128, 4, 2)

@@ -397,6 +397,15 @@ int bfhip_attn_dropout_mask(int B, int H, int Lq, int Lk, float dropout_p, unsig
 int bfhip_upsample2x_nhwc(const void *src, void *dst, int B, int H, int W, int C, int dtype, int dir, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * 3x3 stride-2 pad-1 max pooling of a channels-last bf16 map [N, H, W, C] -> [N, OH, OW, C], OH = (H - 1) / 2 + 1 (the ResNet-50
+ *   stem's nn.MaxPool2d(3, 2, 1); img_backbone = mmdet.ResNet, an external dependency of the reference).  Forward stores the
+ *   winning tap (0..8, torch's scan order and tie / NaN rule) of every element in `tap` (u8, same shape as y); backward is a
+ *   gather over the <= 2 x 2 windows of each input pixel: no atomics, no zero-fill, deterministic.  C % 8 == 0.
+ * --------------------------------------------------------------------------------------- */
+int bfhip_maxpool3x3s2_fwd(const void *x, int N, int H, int W, int C, void *y, unsigned char *tap, void *stream);
+int bfhip_maxpool3x3s2_bwd(const void *dy, const unsigned char *tap, int N, int H, int W, int C, void *dx, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * TransFusion head: box decoding, target assignment and losses on the device  (SURVEY 8 f-3).
  *   Replaces TransFusionBBoxCoder.decode/encode (BF/utils.py:33-96), HungarianAssigner3D.assign with its three costs
  *   and the `.cpu()` + scipy.optimize.linear_sum_assignment round trip (BF/utils.py:128-151,241-284; IoU as
@@ -486,6 +495,15 @@ size_t bfhip_conv2d_dgrad_workspace_bytes(int Cin, int Cout, int KH, int KW);
 int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin, int Cout,
                        int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace, size_t workspace_bytes,
                        void *stream);
+/* The data gradient with the weight already transposed (wt bf16 [Cin][KH][KW][Cout], read-only), and the transposition of a
+ * whole table of weights in one launch -- a training step refreshes all layers' copies once, after the optimizer, instead of
+ * paying a transpose launch inside every bfhip_conv2d_dgrad.  segs_dev: nseg device records of bfhip_conv2d_wt_segment_bytes()
+ * bytes each {u64 src ([Cout][taps][Cin], bf16 or f32), u64 dst, i32 Cout, i32 taps, i32 Cin, i32 src_f32, i64 first_block};
+ * a segment owns ceil(Cin/32) * ceil(Cout/32) * taps blocks, first_block ascending from 0, total_blocks = their sum. */
+int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, void *dx, int ldx, int N, int H, int W, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad, int dil, int out_f32, void *stream);
+int bfhip_conv2d_wt_segment_bytes(void);
+int bfhip_conv2d_weight_transpose_batched(const void *segs_dev, int nseg, long long total_blocks, void *stream);
 size_t bfhip_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
 int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw, int N, int H, int W, int Cin, int Cout,
                        int KH, int KW, int stride, int pad, int dil, int dw_bf16, void *workspace, size_t workspace_bytes,

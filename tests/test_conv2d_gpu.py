@@ -285,3 +285,40 @@ def test_epilogue_statistics_do_not_survive_an_in_place_edit(dev):
         outs.append((bn(yd).float(), bn.running_mean.clone(), bn.running_var.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_transposed_weight_cache_matches_per_call_transpose_and_detects_stale_copies(dev):
+    """conv2d.TransposedWeights: one launch transposes the weights of all layers; a data gradient that uses the cached copy is
+    bit-identical to one that transposes per call; a weight edited through torch afterwards is NOT served from the stale copy."""
+    from bevfusion_amd.conv2d import Conv2dHipWgrad, TransposedWeights
+    torch.manual_seed(3)
+    convs = [Conv2d(64, 96, 3, padding=1, bias=False), Conv2d(40, 72, 1, bias=False), Conv2d(32, 32, 3, stride=2, padding=1, bias=False),
+             Conv2dHipWgrad(64, 128, 1, bias=False), Conv2dHipWgrad(48, 48, 3, padding=1, bias=False)]
+    convs[3].fwd = convs[3].dgrad = "hip"     # the last one keeps the library data gradient: not in the table
+    convs = [c.to(dev).to(memory_format=torch.channels_last).train() for c in convs]
+    convs[1].weight.data = convs[1].weight.data.to(torch.bfloat16)   # a bf16 parameter beside fp32 ones
+    xs = [torch.randn(2, c.in_channels, 24, 28, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c in convs]
+
+    def grads():
+        out = []
+        for c, x in zip(convs, xs):
+            xr = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = c(xr)
+            g = torch.ones_like(y) * 0.5
+            out.append(torch.autograd.grad(y, xr, g)[0])
+        return out
+
+    base = grads()
+    tw = TransposedWeights(convs)
+    assert len(tw.items) == 4 and all(getattr(c.weight, "_bfhip_wt", None) is not None for c in convs[:4])
+    assert getattr(convs[4].weight, "_bfhip_wt", None) is None
+    for a, b in zip(base, grads()):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        convs[0].weight.mul_(2.0)             # version bump: the copy of layer 0 is stale now
+    stale = grads()
+    assert torch.allclose(stale[0].float(), 2.0 * base[0].float(), rtol=2e-2, atol=1e-3)
+    tw.refresh()
+    fresh = grads()
+    assert torch.equal(fresh[0], stale[0]) and torch.equal(fresh[1], base[1])
