@@ -398,9 +398,9 @@ class _ModelWorkload:
             return (N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin)
 
         # every entry: (M, K, Cout, data gradient wanted, input elements, forward on HIP, data gradient on HIP)
-        def spy_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib=False):
+        def spy_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib=False, *more):
             convs.append(shape(x, weight, stride, pad, dil) + (True, not dgrad_lib))
-            return orig_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib)
+            return orig_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib, *more)
 
         def spy_b(x, residual, *a, **k):
             if x.is_cuda and x.dim() == 4:
@@ -408,10 +408,10 @@ class _ModelWorkload:
                 bns.append((x.numel() * x.element_size(), residual is not None, has_partial))
             return orig_b(x, residual, *a, **k)
 
-        def spy_h(ctx, x, weight, stride, pad, dil, dgrad_hip=False):  # library forward, HIP weight gradient (ResNet-50 trunk)
+        def spy_h(ctx, x, weight, stride, pad, dil, dgrad_hip=False, *more):  # library forward, HIP weight gradient (ResNet-50 trunk)
             convs.append(shape(x, weight, stride, pad, dil) + (False, bool(dgrad_hip)))
             hybrid.append(1)
-            return orig_h(ctx, x, weight, stride, pad, dil, dgrad_hip)
+            return orig_h(ctx, x, weight, stride, pad, dil, dgrad_hip, *more)
 
         c2._Conv2dFunction.forward, b2._apply = staticmethod(spy_c), spy_b
         c2._LibConvHipWgradFunction.forward = staticmethod(spy_h)

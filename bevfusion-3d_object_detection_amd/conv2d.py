@@ -26,6 +26,8 @@ MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))  # tiny maps
 # layers with fewer input channels stay on the library: the one such layer of the model (dtransform 8 -> 32, 5x5 stride 4 on the
 # 256 x 704 depth images) has an 8-column data gradient over 4.3 M rows -- 0.30 ms on 64-column tiles; 33.43 vs 33.70 ms per step
 MIN_CIN = int(os.environ.get("BFHIP_CONV2D_MIN_CIN", "16"))
+# residual blocks: the identity branch's gradient is added inside the data gradient of the block's first conv (forward_fork)
+FORK = os.environ.get("BFHIP_CONV_FORK", "1") == "1"
 _WS = {}
 
 # Weight gradients on their own HIP stream (opt-in, BFHIP_WGRAD_SIDE_STREAM=1; bench.py switches it on and joins after the
@@ -124,7 +126,7 @@ def _weight_ohwi(w):
 
 class _Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib=False):
+    def forward(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib=False, fork=False):
         ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the (non-differentiable) statistics output
         x = _as_nhwc_bf16(x)
         N, Cin, H, W = x.shape
@@ -148,13 +150,18 @@ class _Conv2dFunction(torch.autograd.Function):
         ctx.bias_dtype = bias.dtype if bias is not None else None
         if partial is not None:
             ctx.mark_non_differentiable(partial)
+        if fork:
+            # third output: the input again, as a second consumer's handle (the identity branch of a residual block).  Its gradient
+            # arrives in THIS node's backward, where the data gradient's epilogue adds it -- instead of autograd summing the two
+            # gradient paths into x with a separate pass over the tensor
+            return y, partial, x.view_as(x)
         return y, partial
 
     @staticmethod
-    def backward(ctx, dy, _dpartial):
+    def backward(ctx, dy, _dpartial, d_alias=None):
         x, weight = ctx.saved_tensors
         if dy is None:
-            return None, None, None, None, None, None, None, None
+            return d_alias, None, None, None, None, None, None, None, None
         stride, pad, dil = ctx.geom
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = weight.shape
@@ -164,7 +171,12 @@ class _Conv2dFunction(torch.autograd.Function):
         lib = _lib.load()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _lib_dgrad(dy, x, weight, stride, pad, dil) if ctx.dgrad_lib else _hip_dgrad(dy, x, weight, stride, pad, dil)
+            if ctx.dgrad_lib:
+                dx = _lib_dgrad(dy, x, weight, stride, pad, dil)
+                if d_alias is not None:
+                    dx = dx + d_alias
+            else:
+                dx = _hip_dgrad(dy, x, weight, stride, pad, dil, d_alias)
         side = None
         if ctx.needs_input_grad[1]:
             dw, side = _launch_wgrad(x, dy, weight, stride, pad, dil)
@@ -174,22 +186,32 @@ class _Conv2dFunction(torch.autograd.Function):
                     db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
             else:
                 db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def _hip_dgrad(dy, x, weight, stride, pad, dil):
+def _hip_dgrad(dy, x, weight, stride, pad, dil, addend=None):
+    """dx of a convolution on csrc/conv2d.hip; `addend` (a second gradient into x, same shape) is added in the kernel's epilogue
+    when the call is one that fuses it (pointwise layer, transposed weight at hand, dense bf16 channels-last addend), otherwise
+    by a torch add."""
     N, Cin, H, W = x.shape
     Cout, _, KH, KW = weight.shape
     stream = _lib.stream_of(x)
     dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
     cached = getattr(weight, "_bfhip_wt", None)  # TransposedWeights: (wt, weight._version, weight.data_ptr()) at refresh time
     if cached is not None and cached[1] == weight._version and cached[2] == weight.data_ptr():
-        _lib.call("bfhip_conv2d_dgrad_wt", dy.data_ptr(), _nhwc_view(dy), cached[0].data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin,
-                  Cout, KH, KW, stride, pad, dil, 0, stream)
+        fuse = (addend is not None and addend.dtype == torch.bfloat16 and addend.shape == dx.shape
+                and addend.is_contiguous(memory_format=torch.channels_last) and addend.data_ptr() % 16 == 0
+                and _lib.load().bfhip_conv2d_dgrad_fuses_addend(KH, KW, stride, pad, 0))
+        _lib.call("bfhip_conv2d_dgrad_wt", dy.data_ptr(), _nhwc_view(dy), cached[0].data_ptr(), _lib.ptr(addend) if fuse else None,
+                  dx.data_ptr(), Cin, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, 0, stream)
+        if addend is not None and not fuse:
+            dx = dx + addend
         return dx
     ws = _workspace(x.device, _lib.load().bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), stream)
     _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
               W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
+    if addend is not None:
+        dx = dx + addend
     return dx
 
 
@@ -290,9 +312,11 @@ def _one(v):
     return v
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, emit_stats=False, dgrad_lib=False):
-    """y = conv2d(x, weight, bias) on the HIP path (bf16, channels-last); returns (y, stat_partial | None)."""
-    return _Conv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats), bool(dgrad_lib))
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, emit_stats=False, dgrad_lib=False, fork=False):
+    """y = conv2d(x, weight, bias) on the HIP path (bf16, channels-last); returns (y, stat_partial | None) and, with `fork`,
+    a third output: x again, for a second consumer whose gradient the data gradient's epilogue adds (see _Conv2dFunction)."""
+    return _Conv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats), bool(dgrad_lib),
+                                 bool(fork))
 
 
 class Conv2d(nn.Conv2d):
@@ -346,3 +370,16 @@ class Conv2dHipWgrad(Conv2d):
                 y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
             return y
         return _LibConvHipWgradFunction.apply(x, self.weight, s, p, d, self.dgrad == "hip")
+
+    def forward_fork(self, x):
+        """(conv(x), x'): x' is x for a second consumer (the identity branch of a residual block); when this layer runs forward and
+        data gradient on the HIP kernels, the gradient that comes back through x' is added in the data gradient's epilogue
+        instead of by a separate pass of autograd's.  Any other case: (self(x), x)."""
+        if (FORK and self.fwd == "hip" and self.dgrad == "hip" and self.bias is None and self.training and torch.is_grad_enabled()
+                and x.requires_grad and x.dtype == torch.bfloat16 and x.dim() == 4 and _nhwc_view(x) is not None
+                and self.hip_eligible(x)):
+            s, p, d = _one(self.stride), _one(self.padding), _one(self.dilation)
+            y, partial, alias = conv2d(x, self.weight, None, s, p, d, True, False, True)
+            y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
+            return y, alias
+        return self(x), x

@@ -125,7 +125,7 @@ template <int WGM, int WGN, int MI, int NI, bool OUT_F32, typename RowMap = RowI
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned char *smem, int tm, long long m0, int n0,
                                                long long M, int Kout, int ldy, const float *__restrict__ bias,
                                                void *__restrict__ y, float *__restrict__ stat_partial,
-                                               RowMap row_map = RowMap()) {
+                                               RowMap row_map = RowMap(), const bf16_t *__restrict__ residual = nullptr) {
   constexpr int NTHREADS = WGM * WGN * 64;
   constexpr int BN = WGN * NI * 32, BM = WGM * MI * 32;
   constexpr int PR = BM / 128;   // statistics partial rows of this tile (one per 128 pixels)
@@ -202,6 +202,38 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned c
     if (m >= M || col >= Kout) continue;
     unsigned char *dst = (unsigned char *)y + ((size_t)row_map(m) * ldy + col) * ESZ;
     const unsigned char *src = smem + row * ROWB + c * 16;
+    if (!OUT_F32 && residual) {
+      // bf16 output + a bf16 addend laid out like the output (the other gradient path into the same tensor): widened, added
+      // to the already rounded result in fp32, rounded once more -- what a separate bf16 add kernel computes
+      const bf16_t *rs = residual + ((size_t)row_map(m) * ldy + col);
+      bf16_t *d16 = (bf16_t *)dst;
+      const bf16_t *s16 = (const bf16_t *)src;
+      if (col + EPC <= Kout && ((((uintptr_t)dst) | ((uintptr_t)rs)) & 15) == 0) {
+        const uint4 a4 = *(const uint4 *)src, b4 = *(const uint4 *)rs;
+        const unsigned a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16);
+          const float hi = __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u);
+          o[q] = rne_bf16(lo) | (rne_bf16(hi) << 16);
+        }
+        *(uint4 *)dst = make_uint4(o[0], o[1], o[2], o[3]);
+        continue;
+      }
+      for (int e = 0; e < EPC && col + e < Kout; e += 2) {
+        if (col + e + 1 < Kout && ((((uintptr_t)(d16 + e)) | ((uintptr_t)(rs + e))) & 3) == 0) {
+          const unsigned a = *(const unsigned *)(s16 + e), b = *(const unsigned *)(rs + e);
+          const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+          const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+          *(unsigned *)(d16 + e) = rne_bf16(lo) | (rne_bf16(hi) << 16);
+        } else {
+          for (int q = e; q < e + 2 && col + q < Kout; ++q)
+            d16[q] = (bf16_t)rne_bf16(__uint_as_float((unsigned)s16[q] << 16) + __uint_as_float((unsigned)rs[q] << 16));
+        }
+      }
+      continue;
+    }
     if (col + EPC <= Kout && (((uintptr_t)dst) & 15) == 0) *(uint4 *)dst = *(const uint4 *)src;
     else
       for (int e = 0; e < EPC && col + e < Kout; ++e) {
@@ -396,7 +428,8 @@ template <int NI, bool OUT_F32, int DIR>
 __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt,
                                                          const float *__restrict__ bias, void *__restrict__ y,
                                                          float *__restrict__ stat_partial, long long M, int C, int ldx, int Kout,
-                                                         int ldw, int ldy, int tiles_m, int tiles_n) {
+                                                         int ldw, int ldy, int tiles_m, int tiles_n,
+                                                         const bf16_t *__restrict__ residual) {
   constexpr int WGN = 2, MI = 2;
   constexpr int BM = 128, BN = NI * 64;
   constexpr int A_BYTES = BM * 128;
@@ -460,7 +493,7 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const bf16_t *__restric
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
   }
-  igemm_epilogue<2, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, M, Kout, ldy, bias, y, stat_partial);
+  igemm_epilogue<2, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, M, Kout, ldy, bias, y, stat_partial, RowIdentity(), residual);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1104,8 +1137,10 @@ BFHIP_EXPORT int bfhip_conv2d_supported(int N, int H, int W, int Cin, int Cout, 
 // rows of the BN-statistics partial buffer the forward writes: stat_partial f32[conv2d_stat_rows][2][Cout]
 BFHIP_EXPORT int bfhip_conv2d_stat_rows(int N, int OH, int OW) { return ceil_div((long long)N * OH * OW, 128); }
 
+static bool pointwise_geom(const ConvGeom &g) { return g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0 && g.transposed != 2; }
+
 static int launch_igemm(const void *x, const void *wt, const float *bias, void *y, float *stat_partial, ConvGeom g, int out_f32,
-                        hipStream_t s, const char *what) {
+                        hipStream_t s, const char *what, const void *residual = nullptr) {
   // tile shapes (see conv_igemm_kernel): 0 = 128 x 64, 1 = 128 x 128, 2 = 256 x 256 (bf16 output, wide GEMMs with at least
   // ~1.5 tiles per CU), 3 = 256 x 128 with 64 x 64 wave tiles and three stages (experiment switch only)
   static const int force_big = getenv("BFHIP_CONV_BIG_TILES") ? 1 : 0;
@@ -1115,7 +1150,9 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
   // 1x1, stride 1, no padding (forward, or the data gradient of such a layer: both are plain GEMMs over the pixel matrix)
   // with a short K: conv_pw_kernel.  BFHIP_CONV_PW_MAXC: largest channel count of the gathered tensor it takes (0 = never)
   static const int pw_maxc = [] { const char *e = getenv("BFHIP_CONV_PW_MAXC"); return e ? atoi(e) : 4096; }();
-  if (g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0 && g.transposed != 2 && g.C <= pw_maxc) {
+  BFHIP_REQUIRE(!residual || (pointwise_geom(g) && g.C <= pw_maxc && !out_f32),
+                "%s: an addend is only fused into the pointwise kernel (1x1, stride 1, no padding, bf16 output)", what);
+  if (pointwise_geom(g) && g.C <= pw_maxc) {
     const int ni = g.Kout > 64 ? 2 : 1, BN = ni * 64;
     const int tiles_m = ceil_div(g.M, 128), tiles_n = ceil_div(g.Kout, BN);
     const size_t stage = (size_t)(128 + BN) * 128, epi = (size_t)128 * BN * (out_f32 ? 4 : 2);
@@ -1129,7 +1166,7 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((conv_pw_kernel<NIV, F32, DIRV>), grid, dim3(256), lds, s, (const bf16_t *)x, (const bf16_t *)wt, bias, y, \
-                       stat_partial, g.M, g.C, g.ldx, g.Kout, g.ldw, g.ldy, tiles_m, tiles_n);                         \
+                       stat_partial, g.M, g.C, g.ldx, g.Kout, g.ldw, g.ldy, tiles_m, tiles_n, (const bf16_t *)residual); \
   } while (0)
 #define BFHIP_PW2(NIV, F32) do { if (g.transposed) BFHIP_PW(NIV, F32, 1); else BFHIP_PW(NIV, F32, 0); } while (0)
     if (ni == 2) { if (out_f32) BFHIP_PW2(2, true); else BFHIP_PW2(2, false); }
@@ -1223,7 +1260,7 @@ BFHIP_EXPORT size_t bfhip_conv2d_dgrad_workspace_bytes(int Cin, int Cout, int KH
 // w: the convolution's weight (transposed into `workspace` first) or, with w == nullptr, `workspace` IS the transposed weight
 static int conv2d_dgrad_impl(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin, int Cout,
                              int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace, size_t workspace_bytes,
-                             hipStream_t s) {
+                             hipStream_t s, const void *residual = nullptr) {
   BFHIP_REQUIRE(bfhip_conv2d_supported(N, H, W, Cin, Cout, KH, KW, stride, pad, dil), "conv2d_dgrad: unsupported geometry");
   BFHIP_REQUIRE(dy && dx && workspace, "conv2d_dgrad: null pointer");
   BFHIP_REQUIRE(workspace_bytes >= bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), "conv2d_dgrad: workspace too small");
@@ -1266,7 +1303,8 @@ static int conv2d_dgrad_impl(const void *dy, int ldg, const void *w, void *dx, i
         if (c.Hc > 0 && c.Wc > 0) ++g.ncls;
       }
   }
-  const int rc = launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad");
+  BFHIP_REQUIRE(((uintptr_t)residual % 4) == 0, "conv2d_dgrad: misaligned addend");
+  const int rc = launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad", residual);
   prof_end(&ps);
   return rc;
 }
@@ -1279,11 +1317,18 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
                            (hipStream_t)stream_);
 }
 
-// the same with the weight already transposed: wt bf16 [Cin][KH][KW][Cout] (bfhip_conv2d_weight_transpose_batched); read-only
-BFHIP_EXPORT int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, void *dx, int ldx, int N, int H, int W, int Cin,
-                                       int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, void *stream_) {
+// the same with the weight already transposed: wt bf16 [Cin][KH][KW][Cout] (bfhip_conv2d_weight_transpose_batched); read-only.
+// addend (optional, bf16 [N, H, W, Cin] with pixel pitch ldx): dx = data gradient + addend in the kernel's epilogue -- the other
+// gradient path into the same tensor (a residual connection); only for calls the pointwise kernel serves (bfhip_conv2d_dgrad_fuses_addend)
+BFHIP_EXPORT int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, const void *addend, void *dx, int ldx, int N, int H,
+                                       int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32,
+                                       void *stream_) {
   return conv2d_dgrad_impl(dy, ldg, nullptr, dx, ldx, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, out_f32, (void *)wt,
-                           bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), (hipStream_t)stream_);
+                           bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), (hipStream_t)stream_, addend);
+}
+
+BFHIP_EXPORT int bfhip_conv2d_dgrad_fuses_addend(int KH, int KW, int stride, int pad, int out_f32) {
+  return KH == 1 && KW == 1 && stride == 1 && pad == 0 && !out_f32 ? 1 : 0;
 }
 
 BFHIP_EXPORT int bfhip_conv2d_wt_segment_bytes(void) { return (int)sizeof(WtSeg); }

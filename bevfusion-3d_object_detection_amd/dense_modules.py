@@ -80,8 +80,12 @@ class _Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
+        if self.downsample is None and hasattr(self.conv1, "forward_fork"):
+            out, identity = self.conv1.forward_fork(x)   # the identity's gradient is added in conv1's data gradient
+            out = self.bn1(out, relu=True)
+        else:
+            identity = x if self.downsample is None else self.downsample(x)
+            out = self.bn1(self.conv1(x), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         return self.bn3(self.conv3(out), residual=identity, relu=True)  # BN + identity + ReLU in one pass
 

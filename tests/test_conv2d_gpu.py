@@ -322,3 +322,40 @@ def test_transposed_weight_cache_matches_per_call_transpose_and_detects_stale_co
     tw.refresh()
     fresh = grads()
     assert torch.equal(fresh[0], stale[0]) and torch.equal(fresh[1], base[1])
+
+
+@pytest.mark.parametrize("cached", [True, False], ids=["fused_addend", "torch_add"])
+def test_forked_conv_adds_the_identity_gradient_in_its_data_gradient(dev, cached):
+    """Residual block entry: x feeds a 1x1 conv and the identity branch.  Conv2dHipWgrad.forward_fork returns (conv(x), x') and the
+    gradient that reaches x' is added inside the data gradient's epilogue (with the transposed weight at hand) or by a torch add
+    (without) -- both must equal dgrad + identity gradient of the plain graph, computed in fp32 on the CPU."""
+    from bevfusion_amd.conv2d import Conv2dHipWgrad, TransposedWeights
+    N, H, W, Cin, Cout = 3, 33, 47, 256, 64
+    x, w, _ = _case((N, H, W, Cin, Cout, 1, 1, 0, 1, False), seed=11)
+    rng = np.random.default_rng(12)
+    gy = _bf16_round(rng.standard_normal((N, Cout, H, W)).astype(np.float32))
+    gi = _bf16_round(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (F.conv2d(xr, wr) * gy).sum().backward()
+    dx_ref = xr.grad + gi
+    conv = Conv2dHipWgrad(Cin, Cout, 1, bias=False).to(dev).train()
+    conv.fwd = conv.dgrad = "hip"
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    conv.to(memory_format=torch.channels_last)
+    if cached:
+        TransposedWeights([conv])
+    xg = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y, ident = conv.forward_fork(xg)
+    assert ident is not xg and ident.data_ptr() == xg.data_ptr() and getattr(y, "_bfhip_stat_partial", None) is not None
+    cl = lambda t: t.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    torch.autograd.backward([y, ident], [cl(gy), cl(gi)])
+    assert _rel(xg.grad.float().cpu(), dx_ref) < 1e-2 and _l2(xg.grad.float().cpu(), dx_ref) < 4e-3
+    assert _rel(conv.weight.grad.cpu(), wr.grad) < 1e-4
+    # only one of the two outputs used: the other gradient is absent, not zero-filled
+    xg2 = xg.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2, ident2 = conv.forward_fork(xg2)
+    ident2.backward(cl(gi))
+    assert torch.equal(xg2.grad, cl(gi))
