@@ -55,6 +55,7 @@ DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd
 # timed region also measures the wait for CUs the other queues hold.  Roofline fractions are computed from
 # `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side streams off
 # (one queue, nothing beside them) -- the number a rocprofv3 kernel trace reproduces.
+HOST_SLEEP_US = int(os.environ.get("BENCH_HOST_SLEEP_US", "0"))
 LIDAR_OPS = ("hard_voxelize", "spconv_fwd", "spconv_bwd", "spconv_wgrad", "spconv_wgrad_main", "rulebook")
 NO_WORK = os.environ.get("BENCH_NO_WORK") == "1"  # counter passes under rocprofv3: warm-up + timed steps only, nothing else
 ISOLATED_STEPS = 0 if NO_WORK else int(os.environ.get("BENCH_ISOLATED_STEPS", "5"))
@@ -280,6 +281,8 @@ class _ModelWorkload:
         self.opt.step()
 
     def _eager_step(self):
+        if HOST_SLEEP_US:  # experiment: is the step bound by its host side?  (a host-bound step grows by the sleep, a GPU-bound one does not)
+            time.sleep(HOST_SLEEP_US * 1e-6)
         self.opt.zero_grad() if self.master_weights else self.opt.zero_grad(set_to_none=True)
         loss = self._forward_backward(self.gts)
         self._update()

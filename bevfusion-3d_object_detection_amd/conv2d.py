@@ -150,6 +150,11 @@ class _Conv2dFunction(torch.autograd.Function):
         ctx.bias_dtype = bias.dtype if bias is not None else None
         if partial is not None:
             ctx.mark_non_differentiable(partial)
+        ctx.fork = int(fork)
+        if fork == 2:
+            # third output: x at its even pixels, [N, C, ceil(H/2), ceil(W/2)] (what a stride-2 1x1 shortcut reads).  The gradient
+            # of that compact tensor comes back to THIS node and is added at the even pixels by the data gradient's epilogue
+            return y, partial, x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
         if fork:
             # third output: the input again, as a second consumer's handle (the identity branch of a residual block).  Its gradient
             # arrives in THIS node's backward, where the data gradient's epilogue adds it -- instead of autograd summing the two
@@ -161,6 +166,10 @@ class _Conv2dFunction(torch.autograd.Function):
     def backward(ctx, dy, _dpartial, d_alias=None):
         x, weight = ctx.saved_tensors
         if dy is None:
+            if d_alias is not None and ctx.fork == 2:
+                full = torch.zeros_like(x)
+                full[:, :, ::2, ::2] = d_alias
+                d_alias = full
             return d_alias, None, None, None, None, None, None, None, None
         stride, pad, dil = ctx.geom
         N, Cin, H, W = x.shape
@@ -172,11 +181,9 @@ class _Conv2dFunction(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if ctx.dgrad_lib:
-                dx = _lib_dgrad(dy, x, weight, stride, pad, dil)
-                if d_alias is not None:
-                    dx = dx + d_alias
+                dx = _add_grad(_lib_dgrad(dy, x, weight, stride, pad, dil), d_alias, ctx.fork)
             else:
-                dx = _hip_dgrad(dy, x, weight, stride, pad, dil, d_alias)
+                dx = _hip_dgrad(dy, x, weight, stride, pad, dil, d_alias, 2 if ctx.fork == 2 else 1)
         side = None
         if ctx.needs_input_grad[1]:
             dw, side = _launch_wgrad(x, dy, weight, stride, pad, dil)
@@ -189,30 +196,37 @@ class _Conv2dFunction(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
-def _hip_dgrad(dy, x, weight, stride, pad, dil, addend=None):
-    """dx of a convolution on csrc/conv2d.hip; `addend` (a second gradient into x, same shape) is added in the kernel's epilogue
-    when the call is one that fuses it (pointwise layer, transposed weight at hand, dense bf16 channels-last addend), otherwise
-    by a torch add."""
+def _add_grad(dx, addend, fork):
+    """dx + the second gradient path: on dx's own grid (fork 1) or on the grid of its even pixels (fork 2)."""
+    if addend is None:
+        return dx
+    if fork == 2:
+        dx[:, :, ::2, ::2] += addend
+        return dx
+    return dx + addend
+
+
+def _hip_dgrad(dy, x, weight, stride, pad, dil, addend=None, addend_stride=1):
+    """dx of a convolution on csrc/conv2d.hip; `addend` (a second gradient into x: same shape, or for addend_stride 2 the shape of
+    x[:, :, ::2, ::2]) is added in the kernel's epilogue when the call is one that fuses it (pointwise layer, transposed weight at
+    hand, dense bf16 channels-last addend), otherwise by torch."""
     N, Cin, H, W = x.shape
     Cout, _, KH, KW = weight.shape
     stream = _lib.stream_of(x)
     dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
     cached = getattr(weight, "_bfhip_wt", None)  # TransposedWeights: (wt, weight._version, weight.data_ptr()) at refresh time
     if cached is not None and cached[1] == weight._version and cached[2] == weight.data_ptr():
-        fuse = (addend is not None and addend.dtype == torch.bfloat16 and addend.shape == dx.shape
+        want = (N, Cin, (H + 1) // 2, (W + 1) // 2) if addend_stride == 2 else (N, Cin, H, W)
+        fuse = (addend is not None and addend.dtype == torch.bfloat16 and tuple(addend.shape) == want
                 and addend.is_contiguous(memory_format=torch.channels_last) and addend.data_ptr() % 16 == 0
                 and _lib.load().bfhip_conv2d_dgrad_fuses_addend(KH, KW, stride, pad, 0))
         _lib.call("bfhip_conv2d_dgrad_wt", dy.data_ptr(), _nhwc_view(dy), cached[0].data_ptr(), _lib.ptr(addend) if fuse else None,
-                  dx.data_ptr(), Cin, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, 0, stream)
-        if addend is not None and not fuse:
-            dx = dx + addend
-        return dx
+                  addend_stride, dx.data_ptr(), Cin, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, 0, stream)
+        return dx if fuse else _add_grad(dx, addend, addend_stride)
     ws = _workspace(x.device, _lib.load().bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), stream)
     _lib.call("bfhip_conv2d_dgrad", dy.data_ptr(), _nhwc_view(dy), _weight_ohwi(weight).data_ptr(), dx.data_ptr(), Cin, N, H,
               W, Cin, Cout, KH, KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
-    if addend is not None:
-        dx = dx + addend
-    return dx
+    return _add_grad(dx, addend, addend_stride)
 
 
 def _lib_dgrad(dy, x, weight, stride, pad, dil):
@@ -271,7 +285,7 @@ class TransposedWeights:
         for m in modules:
             if not isinstance(m, Conv2d) or m.groups != 1 or not m.weight.is_cuda:
                 continue
-            if isinstance(m, Conv2dHipWgrad) and m.dgrad != "hip":
+            if isinstance(m, Conv2dHipWgrad) and m.dgrad != "hip" and not m.cache_wt:
                 continue
             w = m.weight
             if w.dtype not in (torch.bfloat16, torch.float32) or not w.permute(0, 2, 3, 1).is_contiguous():
@@ -316,7 +330,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, emit_stats=Fal
     """y = conv2d(x, weight, bias) on the HIP path (bf16, channels-last); returns (y, stat_partial | None) and, with `fork`,
     a third output: x again, for a second consumer whose gradient the data gradient's epilogue adds (see _Conv2dFunction)."""
     return _Conv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats), bool(dgrad_lib),
-                                 bool(fork))
+                                 int(fork))
 
 
 class Conv2d(nn.Conv2d):
@@ -359,6 +373,7 @@ class Conv2dHipWgrad(Conv2d):
 
     fwd = "lib"
     dgrad = "lib"
+    cache_wt = False  # keep a transposed copy of the weight although `dgrad` is "lib" (a stride-2 shortcut run through forward_unstrided)
 
     def forward(self, x):
         if self.bias is not None or not self.training or not self.hip_eligible(x):
@@ -371,15 +386,26 @@ class Conv2dHipWgrad(Conv2d):
             return y
         return _LibConvHipWgradFunction.apply(x, self.weight, s, p, d, self.dgrad == "hip")
 
-    def forward_fork(self, x):
+    def forward_fork(self, x, subsample=1):
         """(conv(x), x'): x' is x for a second consumer (the identity branch of a residual block); when this layer runs forward and
         data gradient on the HIP kernels, the gradient that comes back through x' is added in the data gradient's epilogue
-        instead of by a separate pass of autograd's.  Any other case: (self(x), x)."""
+        instead of by a separate pass of autograd's.  subsample=2: x' is x[:, :, ::2, ::2] (dense), the input of a stride-2 1x1
+        shortcut; its (compact) gradient is added at the even pixels.  Any other case: (self(x), x) / (self(x), None)."""
         if (FORK and self.fwd == "hip" and self.dgrad == "hip" and self.bias is None and self.training and torch.is_grad_enabled()
                 and x.requires_grad and x.dtype == torch.bfloat16 and x.dim() == 4 and _nhwc_view(x) is not None
                 and self.hip_eligible(x)):
             s, p, d = _one(self.stride), _one(self.padding), _one(self.dilation)
-            y, partial, alias = conv2d(x, self.weight, None, s, p, d, True, False, True)
+            y, partial, alias = conv2d(x, self.weight, None, s, p, d, True, False, 2 if subsample == 2 else 1)
             y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
             return y, alias
-        return self(x), x
+        return self(x), (x if subsample == 1 else None)
+
+    def forward_unstrided(self, x_sub):
+        """This (1x1, stride-s, unpadded) layer applied to its input ALREADY subsampled (x[:, :, ::s, ::s], dense): the same values
+        as self(x), computed as a stride-1 pointwise convolution entirely on the HIP kernels (forward with BatchNorm statistics,
+        data gradient on the compact grid, weight gradient)."""
+        assert self.kernel_size == (1, 1) and _one(self.padding) == 0 and self.bias is None
+        y, partial = conv2d(x_sub, self.weight, None, 1, 0, 1, torch.is_grad_enabled())
+        if partial is not None:
+            y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
+        return y

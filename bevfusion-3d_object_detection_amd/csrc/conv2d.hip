@@ -114,18 +114,28 @@ struct RowIdentity {
 struct RowParityClass {
   int Hc, Wc, H, W, h0, w0, stride;
   __device__ __forceinline__ long long operator()(long long m) const {
-    const int n = (int)(m / ((long long)Hc * Wc));
-    const int rem = (int)(m - (long long)n * Hc * Wc);
-    const int i = rem / Wc, j = rem - i * Wc;
-    return ((long long)n * H + h0 + i * stride) * W + w0 + j * stride;
+    // 32-bit arithmetic: every entry point requires N * H * W * pitch < 2^31 (a 64-bit division is ~5x the instructions, and
+    // this runs once per 16-byte store)
+    const unsigned mu = (unsigned)m, hw = (unsigned)(Hc * Wc);
+    const unsigned n = mu / hw, rem = mu - n * hw;
+    const unsigned i = rem / (unsigned)Wc, j = rem - i * (unsigned)Wc;
+    return (long long)((n * (unsigned)H + h0 + i * stride) * (unsigned)W + w0 + j * stride);
   }
+};
+
+// A second gradient path into the tensor the epilogue writes (residual connections): bf16, dense (pixel pitch `ld`), on the
+// output's own pixel grid (sub == 1) or on the grid of its even pixels [N, ceil(H/2), ceil(W/2)] (sub == 2: the gradient of a
+// stride-2 1x1 shortcut, which only reaches the pixels with even h and w)
+struct Addend {
+  const bf16_t *p;
+  int sub, ld, H, W;
 };
 
 template <int WGM, int WGN, int MI, int NI, bool OUT_F32, typename RowMap = RowIdentity>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned char *smem, int tm, long long m0, int n0,
                                                long long M, int Kout, int ldy, const float *__restrict__ bias,
                                                void *__restrict__ y, float *__restrict__ stat_partial,
-                                               RowMap row_map = RowMap(), const bf16_t *__restrict__ residual = nullptr) {
+                                               RowMap row_map = RowMap(), Addend add = Addend{nullptr, 0, 0, 0, 0}) {
   constexpr int NTHREADS = WGM * WGN * 64;
   constexpr int BN = WGN * NI * 32, BM = WGM * MI * 32;
   constexpr int PR = BM / 128;   // statistics partial rows of this tile (one per 128 pixels)
@@ -202,10 +212,21 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[MI][NI], unsigned c
     if (m >= M || col >= Kout) continue;
     unsigned char *dst = (unsigned char *)y + ((size_t)row_map(m) * ldy + col) * ESZ;
     const unsigned char *src = smem + row * ROWB + c * 16;
-    if (!OUT_F32 && residual) {
-      // bf16 output + a bf16 addend laid out like the output (the other gradient path into the same tensor): widened, added
-      // to the already rounded result in fp32, rounded once more -- what a separate bf16 add kernel computes
-      const bf16_t *rs = residual + ((size_t)row_map(m) * ldy + col);
+    const bf16_t *rs = nullptr;
+    if (!OUT_F32 && add.p) {
+      if (add.sub == 2) {  // addend on the even-pixel grid: rows with odd h or w receive nothing from it
+        const unsigned mu = (unsigned)row_map(m), hw = (unsigned)(add.H * add.W);
+        const unsigned n = mu / hw, rem = mu - n * hw;
+        const unsigned h = rem / (unsigned)add.W, w = rem - h * (unsigned)add.W;
+        if (((h | w) & 1u) == 0)
+          rs = add.p + ((size_t)((n * (unsigned)((add.H + 1) >> 1) + (h >> 1)) * (unsigned)((add.W + 1) >> 1) + (w >> 1)) * add.ld + col);
+      } else {
+        rs = add.p + ((size_t)row_map(m) * add.ld + col);
+      }
+    }
+    if (rs) {
+      // bf16 output + bf16 addend (the other gradient path into the same tensor): widened, added to the already rounded
+      // result in fp32, rounded once more -- what a separate bf16 add kernel computes
       bf16_t *d16 = (bf16_t *)dst;
       const bf16_t *s16 = (const bf16_t *)src;
       if (col + EPC <= Kout && ((((uintptr_t)dst) | ((uintptr_t)rs)) & 15) == 0) {
@@ -289,6 +310,27 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
   const long long m0 = (long long)tm * BM;
   const int n0 = tn * BN;
 
+  if (MODE == 2 && nq == 0) {
+    // no tap reaches this parity class (e.g. three of the four classes of a 1x1 stride-2 layer): its gradient is zero -- plain
+    // 16-byte zero stores, no staging, no accumulators
+    constexpr int ESZ = OUT_F32 ? 4 : 2, EPC = 16 / ESZ, CPR = BN / EPC;
+    const RowParityClass rm{pc.Hc, pc.Wc, g.OH, g.OW, pc.h0, pc.w0, g.stride};
+    for (int idx = tid; idx < BM * CPR; idx += NTHREADS) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const long long m = m0 + row;
+      const int col = n0 + c * EPC;
+      if (m >= M || col >= g.Kout) continue;
+      unsigned char *dst = (unsigned char *)y + ((size_t)rm(m) * g.ldy + col) * ESZ;
+      if (col + EPC <= g.Kout && (((uintptr_t)dst) & 15) == 0) *(uint4 *)dst = make_uint4(0u, 0u, 0u, 0u);
+      else
+        for (int e = 0; e < EPC && col + e < g.Kout; ++e) {
+          if (OUT_F32) ((float *)dst)[e] = 0.f;
+          else ((bf16_t *)dst)[e] = 0;
+        }
+    }
+    return;
+  }
+
   for (int q = tid; q < nq; q += NTHREADS) {
     int k = q * 8;
     int tap = k / g.C, ci = k - tap * g.C;
@@ -314,18 +356,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
     rok[i] = m < M;
     long long mm = rok[i] ? m : 0;
     int n, oh, ow;
+    const unsigned mu = (unsigned)mm;  // rows < 2^31 (entry-point precondition): 32-bit divisions
     if (MODE == 2) {
-      const int Hc = pc.Hc, Wc = pc.Wc;
-      n = (int)(mm / ((long long)Hc * Wc));
-      const int rem = (int)(mm - (long long)n * Hc * Wc);
-      const int ci_ = rem / Wc;
-      oh = pc.h0 + ci_ * g.stride;
-      ow = pc.w0 + (rem - ci_ * Wc) * g.stride;
+      const unsigned hw = (unsigned)(pc.Hc * pc.Wc);
+      const unsigned nn = mu / hw, rem = mu - nn * hw;
+      const unsigned ci_ = rem / (unsigned)pc.Wc;
+      n = (int)nn;
+      oh = pc.h0 + (int)ci_ * g.stride;
+      ow = pc.w0 + (int)(rem - ci_ * (unsigned)pc.Wc) * g.stride;
     } else {
-      n = (int)(mm / ((long long)g.OH * g.OW));
-      const int rem = (int)(mm - (long long)n * g.OH * g.OW);
-      oh = rem / g.OW;
-      ow = rem - oh * g.OW;
+      const unsigned hw = (unsigned)(g.OH * g.OW);
+      const unsigned nn = mu / hw, rem = mu - nn * hw;
+      n = (int)nn;
+      oh = (int)(rem / (unsigned)g.OW);
+      ow = (int)(rem - (unsigned)oh * (unsigned)g.OW);
     }
     nb[i] = n * g.H * g.W;
     hb[i] = TR ? oh + g.pad : oh * g.stride - g.pad;
@@ -428,8 +472,7 @@ template <int NI, bool OUT_F32, int DIR>
 __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt,
                                                          const float *__restrict__ bias, void *__restrict__ y,
                                                          float *__restrict__ stat_partial, long long M, int C, int ldx, int Kout,
-                                                         int ldw, int ldy, int tiles_m, int tiles_n,
-                                                         const bf16_t *__restrict__ residual) {
+                                                         int ldw, int ldy, int tiles_m, int tiles_n, Addend add) {
   constexpr int WGN = 2, MI = 2;
   constexpr int BM = 128, BN = NI * 64;
   constexpr int A_BYTES = BM * 128;
@@ -493,7 +536,7 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const bf16_t *__restric
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
   }
-  igemm_epilogue<2, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, M, Kout, ldy, bias, y, stat_partial, RowIdentity(), residual);
+  igemm_epilogue<2, WGN, MI, NI, OUT_F32>(acc, smem, tm, m0, n0, M, Kout, ldy, bias, y, stat_partial, RowIdentity(), add);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1140,7 +1183,7 @@ BFHIP_EXPORT int bfhip_conv2d_stat_rows(int N, int OH, int OW) { return ceil_div
 static bool pointwise_geom(const ConvGeom &g) { return g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0 && g.transposed != 2; }
 
 static int launch_igemm(const void *x, const void *wt, const float *bias, void *y, float *stat_partial, ConvGeom g, int out_f32,
-                        hipStream_t s, const char *what, const void *residual = nullptr) {
+                        hipStream_t s, const char *what, Addend add = Addend{nullptr, 0, 0, 0, 0}) {
   // tile shapes (see conv_igemm_kernel): 0 = 128 x 64, 1 = 128 x 128, 2 = 256 x 256 (bf16 output, wide GEMMs with at least
   // ~1.5 tiles per CU), 3 = 256 x 128 with 64 x 64 wave tiles and three stages (experiment switch only)
   static const int force_big = getenv("BFHIP_CONV_BIG_TILES") ? 1 : 0;
@@ -1150,7 +1193,7 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
   // 1x1, stride 1, no padding (forward, or the data gradient of such a layer: both are plain GEMMs over the pixel matrix)
   // with a short K: conv_pw_kernel.  BFHIP_CONV_PW_MAXC: largest channel count of the gathered tensor it takes (0 = never)
   static const int pw_maxc = [] { const char *e = getenv("BFHIP_CONV_PW_MAXC"); return e ? atoi(e) : 4096; }();
-  BFHIP_REQUIRE(!residual || (pointwise_geom(g) && g.C <= pw_maxc && !out_f32),
+  BFHIP_REQUIRE(!add.p || (pointwise_geom(g) && g.C <= pw_maxc && !out_f32),
                 "%s: an addend is only fused into the pointwise kernel (1x1, stride 1, no padding, bf16 output)", what);
   if (pointwise_geom(g) && g.C <= pw_maxc) {
     const int ni = g.Kout > 64 ? 2 : 1, BN = ni * 64;
@@ -1166,7 +1209,7 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((conv_pw_kernel<NIV, F32, DIRV>), grid, dim3(256), lds, s, (const bf16_t *)x, (const bf16_t *)wt, bias, y, \
-                       stat_partial, g.M, g.C, g.ldx, g.Kout, g.ldw, g.ldy, tiles_m, tiles_n, (const bf16_t *)residual); \
+                       stat_partial, g.M, g.C, g.ldx, g.Kout, g.ldw, g.ldy, tiles_m, tiles_n, add);                   \
   } while (0)
 #define BFHIP_PW2(NIV, F32) do { if (g.transposed) BFHIP_PW(NIV, F32, 1); else BFHIP_PW(NIV, F32, 0); } while (0)
     if (ni == 2) { if (out_f32) BFHIP_PW2(2, true); else BFHIP_PW2(2, false); }
@@ -1190,6 +1233,10 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
     const double rounds = (double)t / 512.0;
     if (rounds > 1.0 && rounds < 4.0 && rounds - (long long)rounds < 0.15) shape = 0;
   }
+  // less than half a residency round of 128 x 128 tiles (small maps with long K: ResNet layer4's 3x3 layers are 132 tiles of 72 K
+  // steps): 128 x 64 tiles double the workgroups; BFHIP_CONV_SMALL_GRID=0 switches the rule off
+  static const int small_grid = [] { const char *e = getenv("BFHIP_CONV_SMALL_GRID"); return e ? atoi(e) : 1; }();
+  if (small_grid && shape == 1 && g.transposed != 2 && (long long)ceil_div(g.M, 128) * ceil_div(g.Kout, 128) < 256) shape = 0;
   const int BM = shape >= 2 ? 256 : 128, BN = shape == 2 ? 256 : (shape == 0 ? 64 : 128), stages = shape == 3 ? 3 : 2;
   int tiles_m = ceil_div(g.M, BM);
   const int tiles_n = ceil_div(g.Kout, BN);
@@ -1260,7 +1307,7 @@ BFHIP_EXPORT size_t bfhip_conv2d_dgrad_workspace_bytes(int Cin, int Cout, int KH
 // w: the convolution's weight (transposed into `workspace` first) or, with w == nullptr, `workspace` IS the transposed weight
 static int conv2d_dgrad_impl(const void *dy, int ldg, const void *w, void *dx, int ldx, int N, int H, int W, int Cin, int Cout,
                              int KH, int KW, int stride, int pad, int dil, int out_f32, void *workspace, size_t workspace_bytes,
-                             hipStream_t s, const void *residual = nullptr) {
+                             hipStream_t s, const void *addend = nullptr, int addend_stride = 1) {
   BFHIP_REQUIRE(bfhip_conv2d_supported(N, H, W, Cin, Cout, KH, KW, stride, pad, dil), "conv2d_dgrad: unsupported geometry");
   BFHIP_REQUIRE(dy && dx && workspace, "conv2d_dgrad: null pointer");
   BFHIP_REQUIRE(workspace_bytes >= bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), "conv2d_dgrad: workspace too small");
@@ -1303,8 +1350,9 @@ static int conv2d_dgrad_impl(const void *dy, int ldg, const void *w, void *dx, i
         if (c.Hc > 0 && c.Wc > 0) ++g.ncls;
       }
   }
-  BFHIP_REQUIRE(((uintptr_t)residual % 4) == 0, "conv2d_dgrad: misaligned addend");
-  const int rc = launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad", residual);
+  BFHIP_REQUIRE(((uintptr_t)addend % 4) == 0 && (addend_stride == 1 || addend_stride == 2), "conv2d_dgrad: bad addend");
+  const int rc = launch_igemm(dy, workspace, nullptr, dx, nullptr, g, out_f32, s, "conv2d_dgrad",
+                              Addend{(const bf16_t *)addend, addend ? addend_stride : 0, Cin, H, W});
   prof_end(&ps);
   return rc;
 }
@@ -1318,13 +1366,15 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void
 }
 
 // the same with the weight already transposed: wt bf16 [Cin][KH][KW][Cout] (bfhip_conv2d_weight_transpose_batched); read-only.
-// addend (optional, bf16 [N, H, W, Cin] with pixel pitch ldx): dx = data gradient + addend in the kernel's epilogue -- the other
-// gradient path into the same tensor (a residual connection); only for calls the pointwise kernel serves (bfhip_conv2d_dgrad_fuses_addend)
-BFHIP_EXPORT int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, const void *addend, void *dx, int ldx, int N, int H,
-                                       int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32,
-                                       void *stream_) {
+// addend (optional, bf16, dense: pixel pitch Cin): dx = data gradient + addend in the kernel's epilogue -- the other gradient path
+// into the same tensor (a residual connection).  addend_stride 1: addend is [N, H, W, Cin]; 2: addend is [N, ceil(H/2), ceil(W/2), Cin],
+// the gradient of a stride-2 1x1 shortcut over x, and reaches the pixels with even h and w only.  Only for calls the pointwise
+// kernel serves (bfhip_conv2d_dgrad_fuses_addend)
+BFHIP_EXPORT int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, const void *addend, int addend_stride, void *dx,
+                                       int ldx, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                       int out_f32, void *stream_) {
   return conv2d_dgrad_impl(dy, ldg, nullptr, dx, ldx, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, out_f32, (void *)wt,
-                           bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), (hipStream_t)stream_, addend);
+                           bfhip_conv2d_dgrad_workspace_bytes(Cin, Cout, KH, KW), (hipStream_t)stream_, addend, addend_stride);
 }
 
 BFHIP_EXPORT int bfhip_conv2d_dgrad_fuses_addend(int KH, int KW, int stride, int pad, int out_f32) {

@@ -54,6 +54,8 @@ def _resnet_conv(cin, cout, k, stride=1, padding=0, bias=False):
             m.fwd = m.dgrad = "hip"
         elif stride == 1 and cin <= 256:
             m.dgrad = "hip"
+        elif k == 1:
+            m.cache_wt = True   # stride-2 shortcut: run on the subsampled input by _Bottleneck (forward_unstrided)
         return m
     if k == 1:
         cls = Conv2d if mode == "hip" else (Conv2dHipWgrad if mode in ("hipwgrad", "hip3x3+hipwgrad") else nn.Conv2d)
@@ -63,6 +65,7 @@ def _resnet_conv(cin, cout, k, stride=1, padding=0, bias=False):
 
 
 _Conv3x3 = _Conv1x1 = _resnet_conv
+_SHORTCUT_FORK = os.environ.get("BFHIP_SHORTCUT_FORK", "1") == "1"
 
 
 class _Bottleneck(nn.Module):
@@ -80,9 +83,19 @@ class _Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        if self.downsample is None and hasattr(self.conv1, "forward_fork"):
+        ds = self.downsample
+        if ds is None and hasattr(self.conv1, "forward_fork"):
             out, identity = self.conv1.forward_fork(x)   # the identity's gradient is added in conv1's data gradient
             out = self.bn1(out, relu=True)
+        elif (ds is not None and hasattr(self.conv1, "forward_fork") and isinstance(ds[0], Conv2dHipWgrad) and ds[0].stride == (2, 2)
+              and ds[0].kernel_size == (1, 1) and ds[0].padding == (0, 0) and _SHORTCUT_FORK and ds[0].training):
+            # stride-2 1x1 shortcut: conv1 also hands out x at its even pixels (dense); the shortcut runs on that as a stride-1
+            # pointwise conv (HIP forward + statistics, compact data gradient) and its gradient is added at the even pixels in
+            # conv1's data-gradient epilogue -- instead of a library data gradient that zero-fills and writes the full-size
+            # tensor plus autograd's add over it
+            out, x_sub = self.conv1.forward_fork(x, subsample=2)
+            out = self.bn1(out, relu=True)
+            identity = ds(x) if x_sub is None else ds[1](ds[0].forward_unstrided(x_sub))
         else:
             identity = x if self.downsample is None else self.downsample(x)
             out = self.bn1(self.conv1(x), relu=True)

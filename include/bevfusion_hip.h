@@ -500,10 +500,12 @@ int bfhip_conv2d_dgrad(const void *dy, int ldg, const void *w, void *dx, int ldx
  * paying a transpose launch inside every bfhip_conv2d_dgrad.  segs_dev: nseg device records of bfhip_conv2d_wt_segment_bytes()
  * bytes each {u64 src ([Cout][taps][Cin], bf16 or f32), u64 dst, i32 Cout, i32 taps, i32 Cin, i32 src_f32, i64 first_block};
  * a segment owns ceil(Cin/32) * ceil(Cout/32) * taps blocks, first_block ascending from 0, total_blocks = their sum. */
-int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, const void *addend, void *dx, int ldx, int N, int H, int W,
-                          int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, void *stream);
-/* addend (optional, bf16 [N,H,W,Cin], pixel pitch ldx): dx = data gradient + addend in the kernel's epilogue (the second gradient
- * path of a residual connection); accepted only when bfhip_conv2d_dgrad_fuses_addend() says so (1x1, stride 1, no padding, bf16) */
+int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, const void *addend, int addend_stride, void *dx, int ldx, int N,
+                          int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int out_f32, void *stream);
+/* addend (optional, bf16, dense with pixel pitch Cin): dx = data gradient + addend in the kernel's epilogue (the second gradient path
+ * of a residual connection).  addend_stride 1: [N,H,W,Cin]; 2: [N,ceil(H/2),ceil(W/2),Cin], the gradient of a stride-2 1x1 shortcut
+ * over the same tensor -- it reaches the pixels with even h and w only.  Accepted only when bfhip_conv2d_dgrad_fuses_addend() says
+ * so (1x1, stride 1, no padding, bf16 output) */
 int bfhip_conv2d_dgrad_fuses_addend(int KH, int KW, int stride, int pad, int out_f32);
 int bfhip_conv2d_wt_segment_bytes(void);
 int bfhip_conv2d_weight_transpose_batched(const void *segs_dev, int nseg, long long total_blocks, void *stream);

@@ -359,3 +359,56 @@ def test_forked_conv_adds_the_identity_gradient_in_its_data_gradient(dev, cached
         y2, ident2 = conv.forward_fork(xg2)
     ident2.backward(cl(gi))
     assert torch.equal(xg2.grad, cl(gi))
+
+
+@pytest.mark.parametrize("cached", [True, False], ids=["fused_addend", "torch_add"])
+@pytest.mark.parametrize("hw", [(32, 46), (33, 47)], ids=["even", "odd"])
+def test_stride2_shortcut_through_the_subsampled_fork(dev, cached, hw):
+    """Entry of a down-sampling residual block: x feeds conv1 (1x1, stride 1) and a 1x1 stride-2 shortcut.  forward_fork(x, 2)
+    returns conv1(x) and x at its even pixels; the shortcut runs on that as a stride-1 pointwise conv (forward_unstrided) and its
+    compact gradient is added at the even pixels inside conv1's data gradient.  Outputs and all gradients against the plain
+    two-convolution graph in fp32 on the CPU (odd extents: the last row / column is an even pixel)."""
+    from bevfusion_amd.conv2d import Conv2dHipWgrad, TransposedWeights
+    H, W = hw
+    N, Cin, C1, C2 = 2, 128, 64, 256
+    rng = np.random.default_rng(21)
+    x = _bf16_round(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+    w1 = _bf16_round((rng.standard_normal((C1, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32))
+    w2 = _bf16_round((rng.standard_normal((C2, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32))
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    g1 = _bf16_round(rng.standard_normal((N, C1, H, W)).astype(np.float32))
+    g2 = _bf16_round(rng.standard_normal((N, C2, OH, OW)).astype(np.float32))
+    xr, w1r, w2r = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    y1r, y2r = F.conv2d(xr, w1r), F.conv2d(xr, w2r, stride=2)
+    torch.autograd.backward([y1r, y2r], [g1, g2])
+    conv1 = Conv2dHipWgrad(Cin, C1, 1, bias=False)
+    conv1.fwd = conv1.dgrad = "hip"
+    short = Conv2dHipWgrad(Cin, C2, 1, stride=2, bias=False)
+    short.cache_wt = True
+    for c, w in ((conv1, w1), (short, w2)):
+        c.to(dev).train()
+        with torch.no_grad():
+            c.weight.copy_(w)
+        c.to(memory_format=torch.channels_last)
+    if cached:
+        tw = TransposedWeights([conv1, short])
+        assert len(tw.items) == 2
+    cl = lambda t: t.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    xg = cl(x).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1, x_sub = conv1.forward_fork(xg, subsample=2)
+        assert tuple(x_sub.shape) == (N, Cin, OH, OW)
+        y2 = short.forward_unstrided(x_sub)
+    assert _rel(y1.float().cpu(), y1r.detach()) < 1e-2 and _rel(y2.float().cpu(), y2r.detach()) < 1e-2
+    assert getattr(y2, "_bfhip_stat_partial", None) is not None
+    torch.autograd.backward([y1, y2], [cl(g1), cl(g2)])
+    assert _rel(xg.grad.float().cpu(), xr.grad) < 1e-2 and _l2(xg.grad.float().cpu(), xr.grad) < 4e-3
+    assert _rel(conv1.weight.grad.cpu(), w1r.grad) < 1e-4 and _rel(short.weight.grad.cpu(), w2r.grad) < 1e-4
+    # the shortcut alone (conv1's output unused): its gradient must still reach x, at the even pixels only
+    xg2 = xg.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, x_sub2 = conv1.forward_fork(xg2, subsample=2)
+    x_sub2.backward(torch.ones_like(x_sub2))
+    want = torch.zeros_like(xg2)
+    want[:, :, ::2, ::2] = 1
+    assert torch.equal(xg2.grad, want)
