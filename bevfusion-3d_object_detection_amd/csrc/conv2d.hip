@@ -278,8 +278,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // MODE 0: forward gather; 1: data gradient (transposed gather over all taps, rows = all input pixels); 2: data gradient of a
 // strided convolution, one parity class of input pixels per launch: a pixel (ih, iw) is reached only by the taps with
 // kh = (ih + pad) mod stride (mod stride), so the class walks KH*KW / stride^2 of the taps instead of meeting holes at the rest
+//   <2, 2, 2, NI, 1>: ONE stage, at most 128 registers, four workgroups per CU (the pointwise kernel's recipe with the tap
+//                     gather): nothing overlaps inside a workgroup, residency hides the latency -- for the small maps of the
+//                     ResNet-50 trunk, where tiles are few and K loops short (BFHIP_CONV_SINGLE_STAGE)
 template <int WGM, int WGN, int MI, int NI, int STAGES, bool OUT_F32, int MODE>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_igemm_kernel(
+__global__ __launch_bounds__(WGM * WGN * 64, (STAGES == 1 ? 4 : (WGM * WGN > 4 ? 1 : 2))) void conv_igemm_kernel(
     const bf16_t *__restrict__ x, const bf16_t *__restrict__ wt, const float *__restrict__ bias, void *__restrict__ y,
     float *__restrict__ stat_partial, ConvGeom g, int tiles_m, int tiles_n) {
   constexpr bool TR = MODE != 0;
@@ -429,14 +432,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN > 4 ? 1 : 2)) void conv_
     if (s0 < nt) stage(s0, s0);
   int buf = 0, nbuf = STAGES - 1;  // stage holding step t / stage the next DMA goes to
   for (int t = 0; t < nt; ++t) {
+    if (STAGES == 1) {
+      if (t) __syncthreads();  // every wave has consumed step t - 1
+      stage(t, 0);
+    }
     // step t must have landed; the DMA of the (up to STAGES - 2) later steps stays in flight
-    if (STAGES == 2 || nt - 1 - t == 0) wait_vmcnt<0>();
+    if (STAGES <= 2 || nt - 1 - t == 0) wait_vmcnt<0>();
     else if (STAGES == 3 || nt - 1 - t == 1) wait_vmcnt<GL>();
     else wait_vmcnt<2 * GL>();
     __builtin_amdgcn_s_barrier();  // all of step t is in LDS; every wave is done reading step t - 1
     const unsigned char *pA = smem + buf * S_BYTES + aoff, *pB = smem + buf * S_BYTES + boff;
-    if (t + STAGES - 1 < nt) stage(t + STAGES - 1, nbuf);  // before the MFMAs: issuing it after the first K quarter's MFMAs
-                                                           // (address generation in their shadow) measured 5-10 % slower
+    if (STAGES > 1 && t + STAGES - 1 < nt) stage(t + STAGES - 1, nbuf);  // before the MFMAs: issuing it after the first K quarter's
+                                                           // MFMAs (address generation in their shadow) measured 5-10 % slower
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int pos = ((2 * ks + lh) ^ rswz) << 4;
@@ -1237,7 +1244,17 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
   // steps): 128 x 64 tiles double the workgroups; BFHIP_CONV_SMALL_GRID=0 switches the rule off
   static const int small_grid = [] { const char *e = getenv("BFHIP_CONV_SMALL_GRID"); return e ? atoi(e) : 1; }();
   if (small_grid && shape == 1 && g.transposed != 2 && (long long)ceil_div(g.M, 128) * ceil_div(g.Kout, 128) < 256) shape = 0;
-  const int BM = shape >= 2 ? 256 : 128, BN = shape == 2 ? 256 : (shape == 0 ? 64 : 128), stages = shape == 3 ? 3 : 2;
+  // One stage + four workgroups per CU for the 128-row tiles (BFHIP_CONV_SINGLE_STAGE: 0 never, 1 by rule, 2 always).  Residency
+  // hides the load latency when there are enough workgroups to fill it (>= 3 per CU) or the K loop is too short for a ring to reach
+  // steady state (<= 18 steps; the parity classes of a strided data gradient: 1/4 ... 1/stride^2 of the taps each); few tiles
+  // with a long K loop keep the two-stage ring.  Measured, same box (tools/resnet_conv_micro.py / conv_micro.py, us, two-stage ->
+  // one stage): ResNet 3x3 64 ch fwd 48.5 -> 42.8, dgrad 51.6 -> 44.9; 128 ch 44.9 -> 39.5, 52.2 -> 43.8; stride-2 data gradients
+  // 93.5 -> 72.7, 82.2 -> 69.9, 88.1 -> 74.9; SECOND 128 -> 128 fwd 63.6 -> 55.1; shared_conv 198.5 -> 184.9; downsample 80 -> 80
+  // 151.8 -> 128.6; against that 256 ch on 16 x 44 maps (264 tiles, 36 steps) 47.6 -> 52.7 and 512 ch on 8 x 22 66.0 -> 84.4
+  static const int single = [] { const char *e = getenv("BFHIP_CONV_SINGLE_STAGE"); return e ? atoi(e) : 1; }();
+  const long long tiles128 = (long long)ceil_div(g.M, 128) * ceil_div(g.Kout, shape == 0 ? 64 : 128);
+  const bool one_stage = shape <= 1 && single && (single == 2 || g.transposed == 2 || tiles128 >= 768 || (g.nq + 7) / 8 <= 18);
+  const int BM = shape >= 2 ? 256 : 128, BN = shape == 2 ? 256 : (shape == 0 ? 64 : 128), stages = shape == 3 ? 3 : (one_stage ? 1 : 2);
   int tiles_m = ceil_div(g.M, BM);
   const int tiles_n = ceil_div(g.Kout, BN);
   if (g.transposed == 2) {  // row tiles class by class
@@ -1248,7 +1265,11 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
     }
     g.cls[g.ncls].tile0 = tiles_m;
   }
-  const size_t lds = igemm_lds_bytes(BM, BN, stages, g.nq);
+  size_t lds = igemm_lds_bytes(BM, BN, stages, g.nq);
+  if (stages == 1) {  // the epilogue stages the output tile in the same LDS: BM x BN elements
+    const size_t epi = (size_t)BM * BN * (out_f32 ? 4 : 2);
+    if (lds < epi) lds = epi;
+  }
   dim3 grid((unsigned)((long long)tiles_m * tiles_n));
 #define BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, TRV)                                                                    \
   do {                                                                                                                 \
@@ -1264,7 +1285,9 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
 #define BFHIP_IG2(WGMV, WGNV, MIV, NIV, ST, F32) do { if (g.transposed == 2) BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, 2); else if (g.transposed) BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, 1); else BFHIP_IG(WGMV, WGNV, MIV, NIV, ST, F32, 0); } while (0)
   if (shape == 2) BFHIP_IG2(2, 4, 4, 2, 2, false);
   else if (shape == 3) { if (out_f32) BFHIP_IG2(4, 2, 2, 2, 3, true); else BFHIP_IG2(4, 2, 2, 2, 3, false); }
+  else if (shape == 1 && one_stage) { if (out_f32) BFHIP_IG2(2, 2, 2, 2, 1, true); else BFHIP_IG2(2, 2, 2, 2, 1, false); }
   else if (shape == 1) { if (out_f32) BFHIP_IG2(2, 2, 2, 2, 2, true); else BFHIP_IG2(2, 2, 2, 2, 2, false); }
+  else if (one_stage) { if (out_f32) BFHIP_IG2(2, 2, 2, 1, 1, true); else BFHIP_IG2(2, 2, 2, 1, 1, false); }
   else { if (out_f32) BFHIP_IG2(2, 2, 2, 1, 2, true); else BFHIP_IG2(2, 2, 2, 1, 2, false); }
 #undef BFHIP_IG2
 #undef BFHIP_IG

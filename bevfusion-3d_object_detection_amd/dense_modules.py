@@ -37,8 +37,10 @@ from .registry import MODELS
 # statistics passes over the trunk); library data gradient 2.52 ms (with its zero-fill of dx), HIP 2.49 ms, where the HIP side
 # wins every stride-1 layer (1x1: conv_pw_kernel, 20-35 % ahead; 3x3 up to 256 channels: 10-25 % ahead) and loses every stride-2
 # one by 1.5-2.3x (the 1x1 stride-2 shortcuts write three zero pixels out of four through the full tile machinery).  Hence
-#   "tuned" (default): 1x1 stride 1 -> HIP forward + HIP data gradient; 3x3 stride 1 -> library forward, HIP data gradient up to
-#                      256 channels; stride 2 (three 3x3, three shortcuts) -> library both ways
+#   "tuned" (default): 1x1 stride 1 -> HIP forward + HIP data gradient; 3x3 up to 256 channels -> HIP forward (ahead of the library
+#                      by 2-8 % since the one-stage tile variant, plus the statistics pass it saves) and, at stride 1, HIP data
+#                      gradient; the 512-channel 3x3 layers and the stride-2 data gradients -> library; stride-2 1x1 shortcuts run
+#                      on the subsampled input as stride-1 pointwise layers (_Bottleneck.forward)
 #   "hipwgrad": library forward and data gradient everywhere (round 2's default); "lib": the library for everything;
 #   "hip3x3" / "hip" / "hip3x3+hipwgrad": the 3x3 / all / 3x3-only layers entirely on the HIP kernels (round-2 experiments:
 #   34.65 / 35.28 / 34.0-34.3 ms per `full` step against 33.7-33.8 for "hipwgrad")
@@ -52,8 +54,10 @@ def _resnet_conv(cin, cout, k, stride=1, padding=0, bias=False):
         m = Conv2dHipWgrad(cin, cout, k, stride=stride, padding=padding, bias=bias)
         if stride == 1 and k == 1:
             m.fwd = m.dgrad = "hip"
-        elif stride == 1 and cin <= 256:
-            m.dgrad = "hip"
+        elif k == 3 and cin <= 256:
+            m.fwd = "hip"
+            if stride == 1:
+                m.dgrad = "hip"
         elif k == 1:
             m.cache_wt = True   # stride-2 shortcut: run on the subsampled input by _Bottleneck (forward_unstrided)
         return m
