@@ -658,6 +658,8 @@ def main():
 
     if args.vt_fp32:
         os.environ["BENCH_VT_FP32"] = "1"
+        from bevfusion_amd import conv2d as _c2v
+        _c2v.FP32_SPLIT = False  # reference numerics throughout: the head's fp32 island on the library's exact fp32 convolution too
     from bevfusion_amd import _lib
     cls = WORKLOADS[args.workload]
     if cpu_mode:
@@ -838,6 +840,9 @@ def main():
                                                    ", weight gradients" if wl._wgrad_join is not None else ""))
         if hasattr(wl, "vt_bf16"):
             line["config"]["view_transform_conv_dtype"] = "bf16" if wl.vt_bf16 else "fp32 (reference fp32 island)"
+            from bevfusion_amd import conv2d as _c2i
+            line["config"]["head_fp32_conv"] = ("three bf16 products per multiply, fp32 accumulation (2^-16 relative per product)"
+                                                if _c2i.FP32_SPLIT else "library fp32")
         if hasattr(wl, "n_params"):
             line["config"]["trainable_params"] = wl.n_params
         if torch.is_tensor(first_loss) and torch.is_tensor(last_loss):
@@ -855,6 +860,8 @@ def main():
             del wl
             torch.cuda.empty_cache()
             os.environ["BENCH_VT_FP32"] = "1"
+            from bevfusion_amd import conv2d as _c2
+            split_was, _c2.FP32_SPLIT = _c2.FP32_SPLIT, False  # the head's fp32 island on the library's exact fp32 convolution
             wl = cls(dev, args.batch, args.points, seed_base=100 * rank, ddp=False, local_rank=local_rank)
             os.environ["BENCH_VT_FP32"] = "0"
             for _ in range(args.warmup):
@@ -868,7 +875,9 @@ def main():
             line["value_reference_numerics"] = round(args.batch * args.steps / dt2, 3)
             line["ms_per_step_reference_numerics"] = round(dt2 / args.steps * 1e3, 4)
             line["config"]["reference_numerics_region"] = ("second timed region, same steps / warm-up: view-transform conv stacks "
-                                                           "(dtransform, depthnet, downsample) in fp32 with fp32 weights")
+                                                           "(dtransform, depthnet, downsample) in fp32 with fp32 weights, the heat-map "
+                                                           "head's fp32 convolution in exact fp32 (library) instead of three bf16 products")
+            _c2.FP32_SPLIT = split_was
         if world == 1 and not args.no_cpu_baseline and not cpu_mode:
             res = wl.cpu_baseline(args.cpu_frames)
             line["cpu_baseline"] = {"value": round(res[0], 4), "unit": "frames/s", "cores": res[3] if len(res) > 3 else 1,

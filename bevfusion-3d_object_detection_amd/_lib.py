@@ -105,6 +105,7 @@ SIGNATURES = {
     "bfhip_conv2d_dgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_conv2d_dgrad_wt": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_int] * 11 + [_c_vp]),
     "bfhip_conv2d_dgrad_fuses_addend": (_c_int, [_c_int] * 5),
+    "bfhip_split_bf16x3": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_int, _c_vp, _c_int, _c_vp]),
     "bfhip_conv2d_wt_segment_bytes": (_c_int, []),
     "bfhip_conv2d_weight_transpose_batched": (_c_int, [_c_vp, _c_int, ctypes.c_longlong, _c_vp]),
     "bfhip_conv2d_wgrad_workspace_bytes": (_c_sz, [_c_int] * 7),

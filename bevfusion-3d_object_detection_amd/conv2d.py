@@ -267,6 +267,97 @@ class _LibConvHipWgradFunction(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+# fp32 convolutions outside autocast (the reference's fp32 islands: the heat-map head, BF/bevfusion_head.py:218) as THREE bf16
+# products per multiply on the matrix cores: a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with a = a_hi + a_lo (a_hi = bf16(a),
+# a_lo = bf16(a - a_hi)), fp32 accumulation, fp32 result.  Relative error of a product 2^-16 (the dropped a_lo*b_lo term and the
+# rounding of the lo parts) -- between exact fp32 and the TF32 (2^-11) the reference's fp32 convolutions run in on its own
+# hardware by torch's default (torch.backends.cudnn.allow_tf32).  The fp32 MFMA path of the library convolution peaks at
+# 157 TFLOP/s (1.0 ms for the head's 128 -> 128 3x3 layer, forward + both gradients); the three products run at ~3 x the bf16
+# kernels' time.  BFHIP_FP32_CONV=lib: the library's exact fp32 (also what `bench.py`'s reference-numerics region uses).
+FP32_SPLIT = os.environ.get("BFHIP_FP32_CONV", "split") == "split"
+
+
+def _split3(t_nhwc, P, C, chan_order=None, batch_order=None):
+    """fp32 [P, C] dense -> (bf16 [P, 3C] | None, bf16 [3, P, C] | None), blocks hi / lo by the order words (bit k: block k = lo)."""
+    chan = torch.empty((P, 3 * C), dtype=torch.bfloat16, device=t_nhwc.device) if chan_order is not None else None
+    batch = torch.empty((3, P, C), dtype=torch.bfloat16, device=t_nhwc.device) if batch_order is not None else None
+    _lib.call("bfhip_split_bf16x3", t_nhwc.data_ptr(), P, C, _lib.ptr(chan), chan_order or 0, _lib.ptr(batch), batch_order or 0,
+              _lib.stream_of(t_nhwc))
+    return chan, batch
+
+
+_HHL, _HLH = 0b100, 0b010   # block orders [hi, hi, lo] and [hi, lo, hi]
+
+
+class _Conv2dSplitFunction(torch.autograd.Function):
+    """fp32 in, fp32 out, three bf16 products per multiply (see FP32_SPLIT).  Concatenation does the bookkeeping: along the
+    channels for forward / data gradient (x' = [x_hi, x_hi, x_lo], w' = [w_hi, w_lo, w_hi] is ONE convolution with 3 x the
+    channels), along the batch for the weight gradient (a sum over pixels: x'' = [x_hi; x_lo; x_hi], dy'' = [dy_hi; dy_hi; dy_lo])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, emit_stats):
+        ctx.set_materialize_grads(False)
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+        OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+        xn = x.permute(0, 2, 3, 1)
+        if not xn.is_contiguous():
+            xn = xn.contiguous()
+        need_w = ctx.needs_input_grad[1]
+        x_chan, x_batch = _split3(xn, N * H * W, Cin, _HHL, _HLH if need_w else None)
+        wn = weight.detach().permute(0, 2, 3, 1).contiguous().view(Cout * KH * KW, Cin)
+        w_chan, _ = _split3(wn, Cout * KH * KW, Cin, _HLH)          # [Cout*KH*KW, 3 Cin] = the OHWI weight of a conv with 3 Cin channels
+        y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        partial = None
+        if emit_stats:
+            partial = torch.empty((_lib.load().bfhip_conv2d_stat_rows(N, OH, OW), 2, Cout), dtype=torch.float32, device=x.device)
+        b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        _lib.call("bfhip_conv2d_fwd", x_chan.data_ptr(), 3 * Cin, w_chan.data_ptr(), _lib.ptr(b32), y.data_ptr(), Cout, N, H, W, 3 * Cin,
+                  Cout, KH, KW, stride, pad, dil, 1, _lib.ptr(partial), _lib.stream_of(x))
+        ctx.save_for_backward(x_batch, weight)
+        ctx.geom = (stride, pad, dil, N, Cin, H, W)
+        ctx.has_bias = bias is not None
+        if partial is not None:
+            ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, dy, _dpartial):
+        x_batch, weight = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None, None, None, None
+        stride, pad, dil, N, Cin, H, W = ctx.geom
+        Cout, _, KH, KW = weight.shape
+        OH, OW = dy.shape[2], dy.shape[3]
+        lib = _lib.load()
+        gn = dy.float().permute(0, 2, 3, 1)
+        if not gn.is_contiguous():
+            gn = gn.contiguous()
+        stream = _lib.stream_of(gn)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_chan, g_batch = _split3(gn, N * OH * OW, Cout, _HHL if need_x else None, 0b100 if need_w else None)
+        dx = dw = db = None
+        if need_x:
+            # dx = sum over (co, tap) of dy'[.., 3 Cout] * w'' with w'' = [w_hi; w_lo; w_hi] stacked along the output channels
+            wn = weight.detach().permute(0, 2, 3, 1).contiguous().view(Cout * KH * KW, Cin)
+            _, w_stack = _split3(wn, Cout * KH * KW, Cin, None, _HLH)       # [3, Cout*KH*KW, Cin] = OHWI weight with 3 Cout outputs
+            dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=gn.device).permute(0, 3, 1, 2)
+            ws = _workspace(gn.device, lib.bfhip_conv2d_dgrad_workspace_bytes(Cin, 3 * Cout, KH, KW), stream)
+            _lib.call("bfhip_conv2d_dgrad", g_chan.data_ptr(), 3 * Cout, w_stack.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, 3 * Cout,
+                      KH, KW, stride, pad, dil, 1, ws.data_ptr(), ws.numel(), stream)
+        if need_w:
+            dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=gn.device).permute(0, 3, 1, 2)
+            ws = _workspace(gn.device, lib.bfhip_conv2d_wgrad_workspace_bytes(3 * N, OH, OW, Cin, Cout, KH, KW), stream)
+            _lib.call("bfhip_conv2d_wgrad", x_batch.data_ptr(), Cin, g_batch.data_ptr(), Cout, dw.data_ptr(), 3 * N, H, W, Cin, Cout, KH,
+                      KW, stride, pad, dil, 0, ws.data_ptr(), ws.numel(), stream)
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gn.sum(dim=(0, 1, 2))
+        return dx, dw, db, None, None, None, None
+
+
 class TransposedWeights:
     """bf16 [Cin][KH][KW][Cout] copies of the weights of every convolution whose data gradient runs on csrc/conv2d.hip,
     refreshed for ALL layers in one launch (`refresh()`: after the optimizer step).  Without it every data gradient starts with
@@ -353,8 +444,32 @@ class Conv2d(nn.Conv2d):
         return bool(_lib.load().bfhip_conv2d_supported(N, H, W, Cin, self.out_channels, self.kernel_size[0], self.kernel_size[1],
                                                        s, p, d))
 
+    def split_eligible(self, x):
+        """An fp32 convolution outside autocast that the three-product path serves (FP32_SPLIT)."""
+        if not (FP32_SPLIT and ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and self.weight.dtype == torch.float32
+                and not torch.is_autocast_enabled("cuda") and self.groups == 1 and self.padding_mode == "zeros"
+                and not isinstance(self.padding, str)):
+            return False
+        s, p, d = _one(self.stride), _one(self.padding), _one(self.dilation)
+        if s is None or p is None or d is None:
+            return False
+        N, Cin, H, W = x.shape
+        Cout, KH, KW = self.out_channels, self.kernel_size[0], self.kernel_size[1]
+        if N * H * W < MIN_PIXELS or Cin % 8 or Cout % 8 or x.numel() * 3 >= (1 << 31):
+            return False
+        sup = _lib.load().bfhip_conv2d_supported
+        return bool(sup(N, H, W, 3 * Cin, Cout, KH, KW, s, p, d) and sup(N, H, W, Cin, 3 * Cout, KH, KW, s, p, d)
+                    and sup(3 * N, H, W, Cin, Cout, KH, KW, s, p, d))
+
     def forward(self, x):
         if not self.hip_eligible(x):
+            if self.split_eligible(x):
+                emit = self.training and self.bias is None and torch.is_grad_enabled()
+                y, partial = _Conv2dSplitFunction.apply(x, self.weight, self.bias, _one(self.stride), _one(self.padding),
+                                                        _one(self.dilation), emit)
+                if partial is not None:
+                    y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
+                return y
             return super().forward(x)
         emit = self.training and self.bias is None and torch.is_grad_enabled()
         y, partial = conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation), emit)

@@ -1107,6 +1107,33 @@ __global__ __launch_bounds__(256) void conv_weight_transpose_batched_kernel(cons
   }
 }
 
+// fp32 operand -> bf16 pair (hi = bf16(v), lo = bf16(v - hi)), written in the two layouts the three-product fp32 convolution
+// consumes (conv2d.py: _Conv2dSplitFunction): channel blocks [P][3C] and batch blocks [3][P][C]; bit k of an order word says
+// whether block k holds hi (0) or lo (1).  One thread = 8 channels of one pixel.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ src, long long P, int C, bf16_t *__restrict__ chan,
+                                                           int order_chan, bf16_t *__restrict__ batch, int order_batch) {
+  const int cv = C >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P * cv) return;
+  const long long p = t / cv;
+  const int c = (int)(t - p * cv) << 3;
+  const float4 a = *(const float4 *)(src + p * C + c), b = *(const float4 *)(src + p * C + c + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned hi[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = rne_bf16(v[j]);
+    lo[j] = rne_bf16(v[j] - __uint_as_float(hi[j] << 16));
+  }
+  const uint4 H4 = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+  const uint4 L4 = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (chan) *(uint4 *)(chan + p * (3LL * C) + (long long)k * C + c) = ((order_chan >> k) & 1) ? L4 : H4;
+    if (batch) *(uint4 *)(batch + ((long long)k * P + p) * C + c) = ((order_batch >> k) & 1) ? L4 : H4;
+  }
+}
+
 // K pieces (16-byte = 8-channel pieces of one tap) a kernel can hold a tap table for: 4 bytes per piece beside 64 KB of
 // stages under the 80 KB dynamic-LDS attribute of the two-workgroups-per-CU tiles (the 256-wide tiles have 31 KB beside
 // 128 KB, the wide weight-gradient tiles 16 KB beside 144 KB).  C is Cin for forward / weight gradient and Cout for the data
@@ -1402,6 +1429,19 @@ BFHIP_EXPORT int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, 
 
 BFHIP_EXPORT int bfhip_conv2d_dgrad_fuses_addend(int KH, int KW, int stride, int pad, int out_f32) {
   return KH == 1 && KW == 1 && stride == 1 && pad == 0 && !out_f32 ? 1 : 0;
+}
+
+// src f32 [P][C] (dense) -> bf16 pairs hi / lo (v ~ hi + lo to 2^-16 relative): chan (optional) bf16 [P][3C], batch (optional)
+// bf16 [3][P][C]; bit k of order_* = block k holds lo.  C % 8 == 0.
+BFHIP_EXPORT int bfhip_split_bf16x3(const float *src, long long P, int C, void *chan, int order_chan, void *batch, int order_batch,
+                                    void *stream_) {
+  BFHIP_REQUIRE(src && (chan || batch) && P > 0 && C > 0 && C % 8 == 0, "split_bf16x3: bad arguments");
+  BFHIP_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)chan % 16) == 0 && ((uintptr_t)batch % 16) == 0, "split_bf16x3: misaligned tensor");
+  const long long total = P * (C / 8);
+  BFHIP_REQUIRE(total < (1LL << 31) * 256, "split_bf16x3: tensor too large");
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_, src, P, C,
+                     (bf16_t *)chan, order_chan, (bf16_t *)batch, order_batch);
+  return check_launch("split_bf16x3");
 }
 
 BFHIP_EXPORT int bfhip_conv2d_wt_segment_bytes(void) { return (int)sizeof(WtSeg); }

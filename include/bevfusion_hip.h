@@ -509,6 +509,10 @@ int bfhip_conv2d_dgrad_wt(const void *dy, int ldg, const void *wt, const void *a
 int bfhip_conv2d_dgrad_fuses_addend(int KH, int KW, int stride, int pad, int out_f32);
 int bfhip_conv2d_wt_segment_bytes(void);
 int bfhip_conv2d_weight_transpose_batched(const void *segs_dev, int nseg, long long total_blocks, void *stream);
+/* fp32 operand -> bf16 pair hi = bf16(v), lo = bf16(v - hi) (v = hi + lo to 2^-16 relative), in the layouts of the three-product
+ * fp32 convolution (a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores, fp32 accumulation): src f32 [P][C] dense ->
+ * chan (optional) bf16 [P][3C] and batch (optional) bf16 [3][P][C]; bit k of order_* set = block k holds lo.  C % 8 == 0. */
+int bfhip_split_bf16x3(const float *src, long long P, int C, void *chan, int order_chan, void *batch, int order_batch, void *stream);
 size_t bfhip_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
 int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw, int N, int H, int W, int Cin, int Cout,
                        int KH, int KW, int stride, int pad, int dil, int dw_bf16, void *workspace, size_t workspace_bytes,

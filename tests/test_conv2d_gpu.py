@@ -412,3 +412,42 @@ def test_stride2_shortcut_through_the_subsampled_fork(dev, cached, hw):
     want = torch.zeros_like(xg2)
     want[:, :, ::2, ::2] = 1
     assert torch.equal(xg2.grad, want)
+
+
+def test_fp32_convolution_by_three_bf16_products(dev):
+    """An fp32 convolution outside autocast (the heat-map head's fp32 island) runs as three bf16 products per multiply with fp32
+    accumulation (conv2d._Conv2dSplitFunction).  Against an fp64 convolution on the CPU: forward, data gradient and weight
+    gradient within 3e-5 relative (bound: 2^-16 per product; exact fp32 would be ~1e-6, TF32 ~1e-3), statistics handed to
+    the BatchNorm, and the BFHIP_FP32_CONV=lib switch restores the library path."""
+    import bevfusion_amd.conv2d as c2
+    N, H, W, Cin, Cout = 2, 45, 52, 128, 128
+    rng = np.random.default_rng(31)
+    x = torch.from_numpy(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32))
+    gy = torch.from_numpy(rng.standard_normal((N, Cout, H, W)).astype(np.float32))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, padding=1)
+    ref.backward(gy.double())
+    conv = Conv2d(Cin, Cout, 3, padding=1, bias=False).to(dev).train()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert conv.split_eligible(xg) and not conv.hip_eligible(xg)
+    y = conv(xg)
+    assert y.dtype == torch.float32 and getattr(y, "_bfhip_stat_partial", None) is not None
+    y.backward(gy.to(dev))
+    e_y, e_dx, e_dw = _l2(y.detach().cpu(), ref.detach()), _l2(xg.grad.cpu(), xr.grad), _l2(conv.weight.grad.cpu(), wr.grad)
+    assert e_y < 3e-5 and e_dx < 3e-5 and e_dw < 3e-5, (e_y, e_dx, e_dw)
+    assert _rel(y.detach().cpu(), ref.detach()) < 1e-4
+    part = y._bfhip_stat_partial[0]
+    assert torch.allclose(part[:, 0].double().sum(0).cpu(), ref.detach().sum((0, 2, 3)), rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    # bf16 rounding of the operands alone would be ~100x worse: the lo terms matter
+    yb = F.conv2d(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), None, padding=1)
+    assert _l2(yb, ref.detach()) > 30 * e_y
+    old = c2.FP32_SPLIT
+    c2.FP32_SPLIT = False
+    try:
+        assert not conv.split_eligible(xg)
+        assert _l2(conv(xg).detach().cpu(), ref.detach()) < 1e-5
+    finally:
+        c2.FP32_SPLIT = old
