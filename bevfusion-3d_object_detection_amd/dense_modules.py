@@ -70,6 +70,7 @@ def _resnet_conv(cin, cout, k, stride=1, padding=0, bias=False):
 
 _Conv3x3 = _Conv1x1 = _resnet_conv
 _SHORTCUT_FORK = os.environ.get("BFHIP_SHORTCUT_FORK", "1") == "1"
+_HEAD_ROWS = os.environ.get("BFHIP_HEAD_ROWS", "1") == "1"   # prediction heads as GEMMs over [B*L, C] rows (SeparateHead.forward)
 
 
 class _Bottleneck(nn.Module):
@@ -232,7 +233,7 @@ class ConvModule(nn.Module):
             self.bn = BatchNorm2dAct(cout, eps=eps, momentum=momentum, act=act) if norm else None
         else:
             self.conv = nn.Conv1d(cin, cout, k, stride=stride, padding=padding, bias=bias)
-            self.bn = nn.BatchNorm1d(cout, eps=eps, momentum=momentum) if norm else None
+            self.bn = BatchNormRows(cout, eps=eps, momentum=momentum) if norm else None  # an nn.BatchNorm1d (+ fused [M, C] path)
         self.dim, self.act = dim, act
 
     def forward(self, x):
@@ -456,8 +457,33 @@ class SeparateHead(nn.Module):
             self.add_module(head, nn.Sequential(*layers))
         getattr(self, "heatmap")[-1].bias.data.fill_(init_bias)
 
+    def _pointwise(self):
+        return all(isinstance(m, (ConvModule, nn.Conv1d)) and (m.conv if isinstance(m, ConvModule) else m).kernel_size == (1,)
+                   and (m.conv if isinstance(m, ConvModule) else m).stride == (1,) for head in self.heads for m in getattr(self, head))
+
     def forward(self, x):
-        return {head: getattr(self, head)(x) for head in self.heads}
+        """x [B, C, L] -> {head: [B, out, L]}.  With kernel size 1 (the reference's configuration) every layer is a linear map
+        over channels: the stacks run on the row-major [B*L, C] matrix -- a view when x is the decoder's [B, L, C] output
+        transposed -- as GEMMs + the fused row BatchNorm, instead of library Conv1d calls on [B, C, 200] (each of which brings
+        zero-fill / cast helper launches in its backward).  Same parameters, same values."""
+        if not (_HEAD_ROWS and x.is_cuda and x.dim() == 3 and self._pointwise()):
+            return {head: getattr(self, head)(x) for head in self.heads}
+        B, C, L = x.shape
+        rows = x.transpose(1, 2).reshape(B * L, C)
+        out = {}
+        for head in self.heads:
+            h = rows
+            for m in getattr(self, head):
+                if isinstance(m, ConvModule):
+                    h = F.linear(h, m.conv.weight[:, :, 0], m.conv.bias)
+                    if m.bn is not None:
+                        h = m.bn(h, relu=m.act)
+                    elif m.act:
+                        h = F.relu(h)
+                else:
+                    h = F.linear(h, m.weight[:, :, 0], m.bias)
+            out[head] = h.view(B, L, -1).transpose(1, 2)
+        return out
 
 
 @MODELS.register_module()
@@ -521,8 +547,13 @@ class BEVFusionHead(nn.Module):
         top = heatmap.reshape(B, -1).topk(self.num_proposals, dim=-1).indices  # = argsort(descending)[:num_proposals]
         top_class, top_index = top // heatmap.shape[-1], top % heatmap.shape[-1]
         query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1), dim=-1)
-        one_hot = F.one_hot(top_class, num_classes=self.num_classes).permute(0, 2, 1)
-        query_feat = query_feat + self.class_encoding(one_hot.to(query_feat.dtype))
+        one_hot = F.one_hot(top_class, num_classes=self.num_classes)   # [B, P, classes]
+        if _HEAD_ROWS and query_feat.is_cuda and self.class_encoding.kernel_size == (1,):
+            # the k = 1 Conv1d over [B, classes, P] is a GEMM over the rows [B, P, classes]
+            enc = F.linear(one_hot.to(query_feat.dtype), self.class_encoding.weight[:, :, 0], self.class_encoding.bias)
+            query_feat = query_feat + enc.permute(0, 2, 1)
+        else:
+            query_feat = query_feat + self.class_encoding(one_hot.permute(0, 2, 1).to(query_feat.dtype))
         query_pos = bev_pos.gather(index=top_index[:, :, None].expand(-1, -1, 2), dim=1)
         rets = []
         for i in range(self.num_decoder_layers):

@@ -362,3 +362,38 @@ def test_optimizer_paths_agree_and_skip_nonfinite_steps(dev, monkeypatch):
             assert changed == (step != 3), step
     assert float(opts[1]._steps_flat[0]) == 5.0 and float(opts[0].scalars[2]) == 5.0   # the skipped step did not count
     assert float(opts[0].scalars[1]) == 0.0 and float(opts[0].scalars[5]) > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32", "bf16_autocast"])
+def test_prediction_heads_as_row_gemms_match_the_conv1d_stacks(dev, monkeypatch, amp):
+    """SeparateHead (centerpoint_head.py:54-82: Conv1d(k=1) -> BN1d -> ReLU -> Conv1d(k=1) per head) evaluated as GEMMs over the
+    [B*L, C] rows with the fused row BatchNorm against the same module's Conv1d path: outputs, input gradient, parameter
+    gradients and running statistics (fp32: 1e-5; under bf16 autocast: bf16 rounding of the GEMM outputs)."""
+    import copy
+    from bevfusion_amd import dense_modules as dm
+    torch.manual_seed(5)
+    heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2), heatmap=(10, 2))
+    a = dm.SeparateHead(128, heads).to(dev).train()
+    b = copy.deepcopy(a)
+    q = torch.randn(4, 200, 128, device=dev)                     # the decoder's [B, L, C] output ...
+    xa = q.clone().requires_grad_(True)
+    xb = q.clone().requires_grad_(True)
+    outs = []
+    for mod, x, rows in ((a, xa, True), (b, xb, False)):
+        monkeypatch.setattr(dm, "_HEAD_ROWS", rows)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            res = mod(x.transpose(1, 2))                        # ... handed over as [B, C, L]
+        assert all(res[h].shape == (4, heads[h][0], 200) for h in heads)
+        sum((res[h].float() * (i + 1)).sum() for i, h in enumerate(heads)).backward()
+        outs.append(res)
+    tol = dict(rtol=2e-2, atol=2e-2) if amp else dict(rtol=1e-4, atol=1e-5)
+    for h in heads:
+        assert torch.allclose(outs[0][h].float(), outs[1][h].float(), **tol), h
+    assert torch.allclose(xa.grad, xb.grad, rtol=5e-2 if amp else 1e-4, atol=5e-2 if amp else 1e-5)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        scale = float(pb.grad.abs().max()) + 1e-12
+        assert float((pa.grad - pb.grad).abs().max()) <= (3e-2 if amp else 1e-4) * scale, n
+    for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        if "num_batches" not in n:
+            assert torch.allclose(ba, bb, rtol=1e-2 if amp else 1e-4, atol=1e-3 if amp else 1e-6), n
