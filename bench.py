@@ -56,6 +56,15 @@ DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd
 # `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side streams off
 # (one queue, nothing beside them) -- the number a rocprofv3 kernel trace reproduces.
 HOST_SLEEP_US = int(os.environ.get("BENCH_HOST_SLEEP_US", "0"))
+
+
+def _issue_stats(ts):
+    """median / max of the host-side intervals between consecutive steps of the timed region (informational: `ms_per_step` is
+    the synchronised wall time over all K steps; a median well below it means a few steps were held up -- a busy host)."""
+    d = sorted((b - a) * 1e3 for a, b in zip(ts[:-1], ts[1:]))
+    if not d:
+        return None
+    return {"median": round(d[len(d) // 2], 3), "max": round(d[-1], 3), "min": round(d[0], 3)}
 LIDAR_OPS = ("hard_voxelize", "spconv_fwd", "spconv_bwd", "spconv_wgrad", "spconv_wgrad_main", "rulebook")
 NO_WORK = os.environ.get("BENCH_NO_WORK") == "1"  # counter passes under rocprofv3: warm-up + timed steps only, nothing else
 ISOLATED_STEPS = 0 if NO_WORK else int(os.environ.get("BENCH_ISOLATED_STEPS", "5"))
@@ -69,8 +78,8 @@ MFMA_PEAK_F32 = (157.3, "fp32-input MFMA peak 157.3 TFLOP/s (v_mfma_f32_16x16x4_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
     ap.add_argument("--workload", default="full", choices=["full", "lidar_only", "lidar_branch", "camera_only", "hotpath_v1", "dist_selftest"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: --workload dist_selftest (CPU), or a one-GPU rehearsal of the multi-rank path with BENCH_ONE_GPU=1")
@@ -695,6 +704,7 @@ def main():
         for op in _lib.OPS:
             _lib.profile_read(op, reset=True)
     t0 = time.perf_counter()
+    issue_t = [t0]  # host time at which each step's launches had been issued (no sync): shows a disturbed run (median << mean)
     last_loss = None
     dense_steps = 0
     for i in range(args.steps):
@@ -705,6 +715,7 @@ def main():
             _lib.profile_enable(2 if dense else 1)
             dense_steps += dense
         last_loss = wl.step()
+        issue_t.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
     prof = {}
@@ -822,6 +833,7 @@ def main():
                       "nuScenes frames/sec (%s)" % args.workload,
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "step_issue_ms": _issue_stats(issue_t),
             "vs_baseline": None, "dtype": "bf16" if getattr(wl, "amp", False) else "f32", "data": "synthetic",
             "config": {"workload": wl.name, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                        "points_per_frame": args.points, "frustum_rows_kept": wl.nk, "bev_intervals": wl.m,
