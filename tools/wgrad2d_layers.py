@@ -19,14 +19,14 @@ shapes = collections.Counter()
 o1, o2 = c2._Conv2dFunction.forward, c2._LibConvHipWgradFunction.forward
 
 
-def spy1(ctx, x, w, b, s, p, d, e):
+def spy1(ctx, x, w, b, s, p, d, e, *more):
     shapes[(tuple(x.shape), tuple(w.shape), s, p, d)] += 1
-    return o1(ctx, x, w, b, s, p, d, e)
+    return o1(ctx, x, w, b, s, p, d, e, *more)
 
 
-def spy2(ctx, x, w, s, p, d):
+def spy2(ctx, x, w, s, p, d, *more):
     shapes[(tuple(x.shape), tuple(w.shape), s, p, d)] += 1
-    return o2(ctx, x, w, s, p, d)
+    return o2(ctx, x, w, s, p, d, *more)
 
 
 c2._Conv2dFunction.forward, c2._LibConvHipWgradFunction.forward = staticmethod(spy1), staticmethod(spy2)
