@@ -275,6 +275,25 @@ class _LibConvHipWgradFunction(torch.autograd.Function):
 # 157 TFLOP/s (1.0 ms for the head's 128 -> 128 3x3 layer, forward + both gradients); the three products run at ~3 x the bf16
 # kernels' time.  BFHIP_FP32_CONV=lib: the library's exact fp32 (also what `bench.py`'s reference-numerics region uses).
 FP32_SPLIT = os.environ.get("BFHIP_FP32_CONV", "split") == "split"
+_SPLIT_SCOPE = [0]
+
+
+class fp32_island:
+    """Marks an fp32 island of a MIXED-PRECISION step (`with torch.autocast(enabled=False)` inside a bf16-autocast forward, as
+    BF/bevfusion_head.py:218): only inside such a scope do fp32 convolutions take the three-product path.  A model that runs in
+    fp32 throughout keeps the library's exact fp32 convolution everywhere (its gradients are held to fp32-grade tolerances by
+    tests/test_dense_modules_gpu.py: through a deep BN + ReLU stack a 5e-6 forward error flips enough ReLU masks to show)."""
+
+    def __init__(self, mixed):
+        self.mixed = bool(mixed)
+
+    def __enter__(self):
+        _SPLIT_SCOPE[0] += self.mixed
+        return self
+
+    def __exit__(self, *a):
+        _SPLIT_SCOPE[0] -= self.mixed
+        return False
 
 
 def _split3(t_nhwc, P, C, chan_order=None, batch_order=None):
@@ -446,7 +465,7 @@ class Conv2d(nn.Conv2d):
 
     def split_eligible(self, x):
         """An fp32 convolution outside autocast that the three-product path serves (FP32_SPLIT)."""
-        if not (FP32_SPLIT and ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and self.weight.dtype == torch.float32
+        if not (FP32_SPLIT and _SPLIT_SCOPE[0] > 0 and ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and self.weight.dtype == torch.float32
                 and not torch.is_autocast_enabled("cuda") and self.groups == 1 and self.padding_mode == "zeros"
                 and not isinstance(self.padding, str)):
             return False

@@ -23,7 +23,7 @@ from torch import nn
 
 from . import _lib
 from .bn2d import BatchNorm2dAct, BatchNormRows, bn_act
-from .conv2d import Conv2d, Conv2dHipWgrad
+from .conv2d import Conv2d, Conv2dHipWgrad, fp32_island
 from .linear_rows import linear_rows
 from . import attention as split_attention
 from .registry import MODELS
@@ -536,7 +536,8 @@ class BEVFusionHead(nn.Module):
         fusion_feat = self.shared_conv(inputs)
         flat = fusion_feat.reshape(B, fusion_feat.shape[1], -1)
         bev_pos = self.bev_pos.expand(B, -1, -1)
-        with torch.autocast("cuda", enabled=False):
+        mixed = fusion_feat.is_cuda and torch.is_autocast_enabled("cuda")
+        with torch.autocast("cuda", enabled=False), fp32_island(mixed):   # the reference's fp32 island (BF/bevfusion_head.py:218)
             dense_heatmap = self.heatmap_head(fusion_feat.float())
         heatmap = dense_heatmap.detach().sigmoid()
         pad = self.nms_kernel_size // 2

@@ -432,8 +432,10 @@ def test_fp32_convolution_by_three_bf16_products(dev):
     with torch.no_grad():
         conv.weight.copy_(w)
     xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    assert conv.split_eligible(xg) and not conv.hip_eligible(xg)
-    y = conv(xg)
+    assert not conv.split_eligible(xg) and not conv.hip_eligible(xg)     # outside an fp32 island of a mixed-precision step: exact fp32
+    with c2.fp32_island(True):
+        assert conv.split_eligible(xg)
+        y = conv(xg)
     assert y.dtype == torch.float32 and getattr(y, "_bfhip_stat_partial", None) is not None
     y.backward(gy.to(dev))
     e_y, e_dx, e_dw = _l2(y.detach().cpu(), ref.detach()), _l2(xg.grad.cpu(), xr.grad), _l2(conv.weight.grad.cpu(), wr.grad)
@@ -447,7 +449,8 @@ def test_fp32_convolution_by_three_bf16_products(dev):
     old = c2.FP32_SPLIT
     c2.FP32_SPLIT = False
     try:
-        assert not conv.split_eligible(xg)
-        assert _l2(conv(xg).detach().cpu(), ref.detach()) < 1e-5
+        with c2.fp32_island(True):
+            assert not conv.split_eligible(xg)
+            assert _l2(conv(xg).detach().cpu(), ref.detach()) < 1e-5
     finally:
         c2.FP32_SPLIT = old
