@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void attn_lse_kernel(const bf16_t *__restrict_
   const bf16_t *Qb = Q + (size_t)b * dm.Lq * dm.E + h * kD, *Kb = K + (size_t)b * dm.Lk * dm.E + h * kD;
   float m[kMaxQT], l[kMaxQT];
   for (int t = 0; t < kMaxQT; ++t) { m[t] = -INFINITY; l[t] = 0.f; }
+  // the workgroup keeps ALL queries: their MFMA operands stay in registers for the whole key loop (2 VGPRs per 16-query tile)
+  s16x4 qreg[kMaxQT];
+#pragma unroll
+  for (int t = 0; t < kMaxQT; ++t) qreg[t] = (t < NQ && t * 16 + ln < dm.Lq) ? ld4(Qb + (size_t)(t * 16 + ln) * dm.E + lg * 4) : zero4();
   const int key0 = c * kChunk + wave * (kChunk / 4);
   for (int kt = 0; kt < kChunk / 64; ++kt) {
     const int key = key0 + kt * 16 + ln;       // A operand row (key) of this lane
@@ -80,9 +84,7 @@ __global__ __launch_bounds__(256) void attn_lse_kernel(const bf16_t *__restrict_
 #pragma unroll
     for (int t = 0; t < kMaxQT; ++t) {
       if (t >= NQ) continue;
-      const int q = t * 16 + ln;
-      const s16x4 qb = q < dm.Lq ? ld4(Qb + (size_t)q * dm.E + lg * 4) : zero4();
-      f32x4 s = MFMA16(ka, qb, ((f32x4){0.f, 0.f, 0.f, 0.f}));  // S^T[key = kbase + i][q = t*16 + ln]
+      f32x4 s = MFMA16(ka, qreg[t], ((f32x4){0.f, 0.f, 0.f, 0.f}));  // S^T[key = kbase + i][q = t*16 + ln]
       float mx = m[t];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -156,6 +158,10 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const bf16_t *__restrict_
   for (int t = 0; t < kMaxQT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float lq_[kMaxQT];
   for (int t = 0; t < kMaxQT; ++t) lq_[t] = (t < NQ && t * 16 + ln < dm.Lq) ? lb[t * 16 + ln] : 0.f;
+  s16x4 qreg[kMaxQT];  // all query tiles in registers for the whole key loop
+#pragma unroll
+  for (int t = 0; t < kMaxQT; ++t) qreg[t] = (t < NQ && t * 16 + ln < dm.Lq) ? ld4(Qb + (size_t)(t * 16 + ln) * dm.E + lg * 4) : zero4();
+  const unsigned long long seed = eff_seed(dm);
   const int key0 = c * kChunk + wave * (kChunk / 4);
   for (int kt = 0; kt < kChunk / 64; ++kt) {
     const int key = key0 + kt * 16 + ln;
@@ -177,13 +183,12 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const bf16_t *__restrict_
     for (int t = 0; t < kMaxQT; ++t) {
       if (t >= NQ) continue;
       const int q = t * 16 + ln;
-      const s16x4 qb = q < dm.Lq ? ld4(Qb + (size_t)q * dm.E + lg * 4) : zero4();
-      f32x4 s = MFMA16(ka, qb, ((f32x4){0.f, 0.f, 0.f, 0.f}));  // S^T[key][q]
+      f32x4 s = MFMA16(ka, qreg[t], ((f32x4){0.f, 0.f, 0.f, 0.f}));  // S^T[key][q]
       s16x4 pa;                                                  // A operand of P V: A[m = q = ln][k = keys lg*4 + i]
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float p = (kbase + i < dm.Lk && q < dm.Lq) ? __expf(s[i] * dm.scale - lq_[t]) : 0.f;
-        if (DROP) p = keep(eff_seed(dm), ((unsigned)bh * dm.Lq + q) * dm.Lk, kbase + i, dm.thresh24) ? p * dm.inv_keep : 0.f;
+        if (DROP) p = keep(seed, ((unsigned)bh * dm.Lq + q) * dm.Lk, kbase + i, dm.thresh24) ? p * dm.inv_keep : 0.f;
         pa[i] = (short)f2bf(p);
       }
       o[t] = MFMA16(pa, vb, o[t]);  // O[q = t*16 + lg*4 + i][dv = ln]
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *__restrict_
   __syncthreads();
   f32x4 dq[kMaxQT];
   for (int t = 0; t < kMaxQT; ++t) dq[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned long long seed = eff_seed(dm);
   const int key0 = c * kChunk + wave * (kChunk / 4);
   for (int kt = 0; kt < kChunk / 64; ++kt) {
     const int key = key0 + kt * 16 + ln;  // this lane's key as an MFMA row / column index
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *__restrict_
         float p = ok ? __expf(st[i] * dm.scale - lq1) : 0.f;
         float da = dat[i], a = p;
         if (DROP) {
-          const bool kp = keep(eff_seed(dm), rb, kbase + i, dm.thresh24);
+          const bool kp = keep(seed, rb, kbase + i, dm.thresh24);
           da = kp ? da * dm.inv_keep : 0.f;
           a = kp ? p * dm.inv_keep : 0.f;
         }
