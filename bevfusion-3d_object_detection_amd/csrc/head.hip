@@ -169,13 +169,17 @@ __global__ __launch_bounds__(128) void assign_cost_kernel(const float *__restric
 
 // ------------------------------------------------------------------------------------ Hungarian
 // One wave per sample.  rows = the smaller side (scipy transposes when it has more rows than columns).
+// stage_cap: floats of LDS behind the work arrays for a copy of the sample's cost matrix (0 = none).  Every Dijkstra step reads
+// one row of the matrix; from global memory that is a dependent ~1.5 us round trip per step, ~200 steps per sample (0.26 ms for the
+// batch, one wave per sample, on the critical path between the decoder and the losses); from LDS ~0.1 us.
 __global__ __launch_bounds__(64) void hungarian_kernel(const float *__restrict__ cost,
                                                        const int *__restrict__ n_gt, int P, int G, int M,
-                                                       int *__restrict__ assigned, int *__restrict__ status) {
+                                                       int *__restrict__ assigned, int *__restrict__ status, int stage_cap) {
   extern __shared__ double smem[];
   const int b = blockIdx.x, lane = threadIdx.x;
   double *u = smem, *v = u + M, *spc = v + M;
   int *path = (int *)(spc + M), *row4col = path + M, *col4row = row4col + M, *SR = col4row + M, *SC = SR + M;
+  float *cs = (float *)(SC + M);  // [nr][nc] when staged
   int g = n_gt[b];
   g = g < 0 ? 0 : (g > G ? G : g);
   const float *Cb = cost + (size_t)b * P * G;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *__restrict__
   }
   const bool tr = P > g;
   const int nr = tr ? g : P, nc = tr ? P : g;
+  const bool staged = (long long)P * g <= stage_cap;
   for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
   for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; }
   __syncthreads();
@@ -195,10 +200,13 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *__restrict__
   {  // scipy's linear_sum_assignment rejects a matrix with ANY NaN or -inf entry ("matrix contains invalid numeric entries")
     int bad = 0;
     for (int e = lane; e < P * g; e += 64) {
-      const float c = Cb[(size_t)(e / g) * G + (e % g)];
+      const int pp = e / g, gg = e - pp * g;
+      const float c = Cb[(size_t)pp * G + gg];
       bad |= (c != c) || (c == -__builtin_inff());
+      if (staged) cs[tr ? gg * nc + pp : e] = c;  // rows = the smaller side
     }
     err = __any(bad) ? 1 : 0;
+    __syncthreads();
   }
   for (int cur = 0; cur < nr && !err; ++cur) {
     for (int j = lane; j < nc; j += 64) { spc[j] = INF; SC[j] = 0; }
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float *__restrict__
       int bestj = -1, bestfree = 0;
       for (int j = lane; j < nc; j += 64) {
         if (SC[j]) continue;
-        double c = tr ? (double)Cb[(size_t)j * G + i] : (double)Cb[(size_t)i * G + j];
+        double c = staged ? (double)cs[i * nc + j] : (tr ? (double)Cb[(size_t)j * G + i] : (double)Cb[(size_t)i * G + j]);
         double r = minVal + c - ui - v[j];
         double s = spc[j];
         if (r < s) { spc[j] = r; path[j] = i; s = r; }
@@ -657,8 +665,19 @@ BFHIP_EXPORT int bfhip_hungarian(const float *cost, const int32_t *n_gt, int B, 
   const int M = P > G ? P : G;
   BFHIP_REQUIRE(B > 0 && P > 0 && G > 0 && M <= 1024, "hungarian: bad sizes B=%d P=%d G=%d (max side 1024)", B, P, G);
   size_t lds = (size_t)M * (3 * sizeof(double) + 5 * sizeof(int));
+  // the cost matrix of a sample in LDS when it fits beside the work arrays (nuScenes: 200 x <= 100 floats = 80 KB)
+  int stage_cap = 0;
+  if (lds + (size_t)P * G * sizeof(float) <= 150 * 1024) {
+    stage_cap = P * G;
+    lds += (size_t)P * G * sizeof(float);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)hungarian_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(hungarian_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cost, n_gt, P, G, M, assigned,
-                     status);
+                     status, stage_cap);
   return check_launch("hungarian");
 }
 
