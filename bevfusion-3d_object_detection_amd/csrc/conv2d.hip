@@ -1490,6 +1490,11 @@ static int wgrad_shape(long long M, int Cout, int Ktot, long long ohow) {
   if (!wide || Ktot / 8 > 3584 || M < 64 * 6 || ohow < 64) return 0;
   if (Ktot > 128) return 1;
   if (Cout > 128) return 2;
+  // a single 128 x 128 tile of dW over very many pixels (1x1 layers with <= 128 channels on both sides; x^T y of the decoder's
+  // projections): the wide kernel with half of its tile empty still beats the two-stage 128 x 128 kernel, whose 253 workgroups of
+  // 4 waves leave one wave per SIMD (BFHIP_WGRAD_WIDE_SMALL_M: fewest pixels for that, 0 = never)
+  static const long long small_m = [] { const char *e = getenv("BFHIP_WGRAD_WIDE_SMALL_M"); return e ? atoll(e) : 1024LL; }();
+  if (small_m > 0 && M >= small_m) return 1;
   return 0;
 }
 

@@ -16,6 +16,12 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 _WS = {}
 
 
+# bf16 operands: x^T y over K rows IS the weight gradient of a 1x1 convolution over a [1, K, 1, C] map, and csrc/conv2d.hip's
+# weight-gradient kernel (bf16 MFMA, LDS-DMA ring, split over the rows) does it in about a third of the time of csrc/xty.hip's
+# fp32-MFMA kernel (K = 129 600, 128 x 128: ~30 vs 90 us).  BFHIP_XTY_CONV=0: always csrc/xty.hip.
+XTY_CONV = os.environ.get("BFHIP_XTY_CONV", "1") == "1"
+
+
 def xty(x, y):
     """f32[M, N] = x^T y for row-major x [K, M], y [K, N] (same dtype: f32 or bf16)."""
     assert x.dim() == 2 and y.dim() == 2 and x.shape[0] == y.shape[0] and x.dtype == y.dtype and x.dtype in _DT
@@ -24,6 +30,17 @@ def xty(x, y):
     N = y.shape[1]
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     stream = _lib.stream_of(x)
+    if (XTY_CONV and x.dtype == torch.bfloat16 and M % 8 == 0 and N % 8 == 0 and K >= 4096 and K * max(M, N) < (1 << 31)
+            and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and _lib.load().bfhip_conv2d_supported(1, K, 1, N, M, 1, 1, 1, 0, 1)):
+        nbytes = _lib.call_size("bfhip_conv2d_wgrad_workspace_bytes", 1, K, 1, N, M, 1, 1)
+        key = (x.device, stream)
+        ws = _WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _WS[key] = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, device=x.device)
+        # dW[co = M][ci = N] = sum over pixels of dy[pixel][co] * x[pixel][ci]: "dy" = x, "x" = y
+        _lib.call("bfhip_conv2d_wgrad", y.data_ptr(), N, x.data_ptr(), M, out.data_ptr(), 1, K, 1, N, M, 1, 1, 1, 0, 1, 0,
+                  ws.data_ptr(), ws.numel(), stream)
+        return out
     nbytes = _lib.call_size("bfhip_xty_workspace_bytes", K, M, N)
     key = (x.device, stream)
     ws = _WS.get(key)
