@@ -454,7 +454,10 @@ class _ModelWorkload:
             # backward: reduce (dy, x) + apply (dy, x -> dx) [+ y read and d_residual write for residual layers]
             work["bn2d_fwd"] = dict(bound="hbm", bytes=sum(b * ((2 if p else 3) + (1 if r else 0)) for b, r, p in bns),
                                     scope="%d BatchNorm(+residual)(+ReLU) layers per step: statistics, finalize, apply" % len(bns))
-            work["bn2d_bwd"] = dict(bound="hbm", bytes=sum(b * (5 + (2 if r else 0)) for b, r, p in bns),
+            # residual layers: + d_residual written, + the ReLU decisions read twice: as one bit per element (1/16 of a pass) where
+            # the forward stored the bit mask (statistics from a HIP conv: bn2d.RELU_BITS), else from the saved output
+            from bevfusion_amd import bn2d as _b2
+            work["bn2d_bwd"] = dict(bound="hbm", bytes=sum(b * (5 + ((1.125 if (p and _b2.RELU_BITS) else 3) if r else 0)) for b, r, p in bns),
                                     scope="%d layers per step: reduce, finalize, apply" % len(bns))
         return work
 

@@ -112,6 +112,9 @@ SIGNATURES = {
     "bfhip_conv2d_wgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_bn2d_fwd_partials": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +
                                 [_c_vp] * 4 + [_c_vp, _c_int, _c_vp, _c_vp]),
+    "bfhip_bn2d_fwd_partials_mask": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +
+                                     [_c_vp] * 4 + [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
+    "bfhip_bn2d_bwd_mask": (_c_int, [_c_vp] * 5 + [ctypes.c_longlong, _c_int, _c_int] + [_c_vp] * 4 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_adamw_segment_bytes": (_c_int, []),
     "bfhip_adamw_chunk_elems": (_c_int, []),
     "bfhip_adamw_step": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp] + [ctypes.c_float] * 6 + [_c_vp]),

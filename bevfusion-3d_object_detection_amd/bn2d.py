@@ -15,6 +15,8 @@ from torch import nn
 from . import _lib
 
 FUSED_BN2D = os.environ.get("BFHIP_FUSED_BN2D", "1") == "1"  # A/B switch; the torch path has identical semantics
+# residual + ReLU layers fed by a HIP convolution (the bottlenecks' bn3): keep one bit per element for the backward instead of y
+RELU_BITS = os.environ.get("BFHIP_BN2D_RELU_BITS", "1") == "1"
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 _WS = {}
 
@@ -62,7 +64,14 @@ class _BN2dFunction(torch.autograd.Function):
         y = torch.empty_like(x)  # keeps the channels-last strides
         stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         stream = _lib.stream_of(x)
-        if partial is not None:
+        mask = None
+        if partial is not None and RELU_BITS and relu and res is not None and dt == 1 and C % 8 == 0:
+            # residual + ReLU: the backward needs (y > 0) only -- one bit per element instead of the saved output
+            mask = torch.empty((M, C // 8), dtype=torch.uint8, device=x.device)
+            _lib.call("bfhip_bn2d_fwd_partials_mask", x.data_ptr(), res.data_ptr(), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps,
+                      momentum, 1, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(), y.data_ptr(),
+                      partial.data_ptr(), partial.shape[0], _lib.ptr(rows_dev), mask.data_ptr(), stream)
+        elif partial is not None:
             # the producing convolution accumulated the column sums in its epilogue (conv2d.py): no statistics pass
             _lib.call("bfhip_bn2d_fwd_partials", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps,
                       momentum, 1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(),
@@ -72,16 +81,16 @@ class _BN2dFunction(torch.autograd.Function):
             _lib.call("bfhip_bn2d_fwd", x.data_ptr(), _lib.ptr(res), weight.data_ptr(), bias.data_ptr(), M, C, dt, eps, momentum,
                       1 if relu else 0, running_mean.data_ptr(), running_var.data_ptr(), stats.data_ptr(), y.data_ptr(),
                       _lib.ptr(rows_dev), ws.data_ptr(), ws.numel(), stream)
-        keep_y = relu and residual is not None  # otherwise the ReLU mask is recomputed from x in the backward
+        keep_y = relu and residual is not None and mask is None  # otherwise the ReLU mask is recomputed from x in the backward
         ctx.rows_dev = rows_dev
-        ctx.save_for_backward(x, y if keep_y else None, stats, weight)
+        ctx.save_for_backward(x, y if keep_y else None, stats, weight, mask)
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.res_dtype = residual.dtype if residual is not None else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, stats, weight = ctx.saved_tensors
+        x, y, stats, weight, mask = ctx.saved_tensors
         N, C, H, W = x.shape
         M, dt = N * H * W, _DT[x.dtype]
         if dy.dtype != x.dtype:
@@ -92,9 +101,13 @@ class _BN2dFunction(torch.autograd.Function):
         dgb = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         stream = _lib.stream_of(x)
         ws = _workspace(x.device, _ws_bytes(M, C, dt), stream)
-        _lib.call("bfhip_bn2d_bwd", dy.data_ptr(), x.data_ptr(), _lib.ptr(y), stats.data_ptr(), weight.data_ptr(), M, C, dt,
-                  1 if ctx.relu else 0, dx.data_ptr(), _lib.ptr(dres), dgb.data_ptr(), _lib.ptr(ctx.rows_dev), ws.data_ptr(),
-                  ws.numel(), stream)
+        if mask is not None:
+            _lib.call("bfhip_bn2d_bwd_mask", dy.data_ptr(), x.data_ptr(), mask.data_ptr(), stats.data_ptr(), weight.data_ptr(), M, C,
+                      dt, dx.data_ptr(), _lib.ptr(dres), dgb.data_ptr(), _lib.ptr(ctx.rows_dev), ws.data_ptr(), ws.numel(), stream)
+        else:
+            _lib.call("bfhip_bn2d_bwd", dy.data_ptr(), x.data_ptr(), _lib.ptr(y), stats.data_ptr(), weight.data_ptr(), M, C, dt,
+                      1 if ctx.relu else 0, dx.data_ptr(), _lib.ptr(dres), dgb.data_ptr(), _lib.ptr(ctx.rows_dev), ws.data_ptr(),
+                      ws.numel(), stream)
         if dres is not None and ctx.res_dtype != dres.dtype:
             dres = dres.to(ctx.res_dtype)
         return dx, dres, dgb[:C].to(weight.dtype), dgb[C:].to(weight.dtype), None, None, None, None, None, None, None

@@ -302,7 +302,9 @@ __global__ __launch_bounds__(kFinThreads) void bn2d_finalize_kernel(const float 
 template <typename T, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T *__restrict__ x, const T *__restrict__ res,
                                                          const float *__restrict__ stats, long long M, int C, Map mp,
-                                                         T *__restrict__ y) {
+                                                         T *__restrict__ y, unsigned char *__restrict__ relu_mask) {
+  // relu_mask (optional, bf16 + residual + ReLU): one BIT per element, [M][C / 8] bytes -- what the backward needs of y (y > 0);
+  // reading it instead of y saves two passes over the tensor per residual layer (bfhip_bn2d_bwd_mask)
   constexpr int V = Vec<T>::V;
   const int t = threadIdx.x, cv = blockIdx.y * mp.Lb + t % mp.Lb, rl = t / mp.Lb;
   const bool live = rl < mp.R && cv * V < C;
@@ -322,37 +324,46 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const T *__restrict__ x
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+      unsigned bits = 0;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float o = v[u][j] * a[j] + b[j];
         if (RES) o += q[u][j];
+        if (o > 0.f) bits |= 1u << j;
         v[u][j] = (RELU && !(o > 0.f)) ? 0.f : o;
       }
       Vec<T>::store(y + (size_t)(r + (long long)u * mp.R) * C + col, v[u]);
+      if (V == 8 && relu_mask) relu_mask[(size_t)(r + (long long)u * mp.R) * (C >> 3) + cv] = (unsigned char)bits;
     }
   }
   for (; r < r1; r += mp.R) {
     float v[V], q[V];
     Vec<T>::load(x + (size_t)r * C + col, v);
     if (RES) Vec<T>::load(res + (size_t)r * C + col, q);
+    unsigned bits = 0;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float o = v[j] * a[j] + b[j];
       if (RES) o += q[j];
+      if (o > 0.f) bits |= 1u << j;
       v[j] = (RELU && !(o > 0.f)) ? 0.f : o;
     }
     Vec<T>::store(y + (size_t)r * C + col, v);
+    if (V == 8 && relu_mask) relu_mask[(size_t)r * (C >> 3) + cv] = (unsigned char)bits;
   }
 }
 
-// MASK: 0 = no ReLU, 1 = ReLU mask recomputed from x (a*x + b > 0), 2 = ReLU mask from the saved output y
+// MASK: 0 = no ReLU, 1 = ReLU mask recomputed from x (a*x + b > 0), 2 = ReLU mask from the saved output y, 3 = from the bit mask
+// the forward stored (yv[0] carries the byte of this 8-channel vector)
 template <typename T, int MASK>
 __device__ __forceinline__ void masked_grad(float *g, const float *xv, const float *yv, const float *a, const float *b) {
   constexpr int V = Vec<T>::V;
+  const unsigned bits = MASK == 3 ? __float_as_uint(yv[0]) : 0u;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     if (MASK == 1 && !(xv[j] * a[j] + b[j] > 0.f)) g[j] = 0.f;
     if (MASK == 2 && !(yv[j] > 0.f)) g[j] = 0.f;
+    if (MASK == 3 && !((bits >> j) & 1u)) g[j] = 0.f;
   }
 }
 
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T *__restric
         Vec<T>::load(dy + off, g[u]);
         Vec<T>::load(x + off, xv[u]);
         if (MASK == 2) Vec<T>::load(y + off, yv[u]);
+        if (MASK == 3) yv[u][0] = __uint_as_float(((const unsigned char *)y)[(size_t)(r + (long long)u * mp.R) * (C >> 3) + cv]);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -402,6 +414,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const T *__restric
       Vec<T>::load(dy + off, g);
       Vec<T>::load(x + off, xv);
       if (MASK == 2) Vec<T>::load(y + off, yv);
+      if (MASK == 3) yv[0] = __uint_as_float(((const unsigned char *)y)[(size_t)r * (C >> 3) + cv]);
       masked_grad<T, MASK>(g, xv, yv, a, b);
 #pragma unroll
       for (int j = 0; j < V; ++j) { s0[j] += g[j]; s1[j] += g[j] * (xv[j] - mean[j]); }
@@ -441,6 +454,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T *__restrict
       Vec<T>::load(dy + off, g[u]);
       Vec<T>::load(x + off, xv[u]);
       if (MASK == 2) Vec<T>::load(y + off, yv[u]);
+      if (MASK == 3) yv[u][0] = __uint_as_float(((const unsigned char *)y)[(size_t)(r + (long long)u * mp.R) * (C >> 3) + cv]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -458,6 +472,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const T *__restrict
     Vec<T>::load(dy + off, g);
     Vec<T>::load(x + off, xv);
     if (MASK == 2) Vec<T>::load(y + off, yv);
+    if (MASK == 3) yv[0] = __uint_as_float(((const unsigned char *)y)[(size_t)r * (C >> 3) + cv]);
     masked_grad<T, MASK>(g, xv, yv, a, b);
     if (DRES) Vec<T>::store(dres + off, g);
 #pragma unroll
@@ -496,10 +511,10 @@ inline Map make_map(long long M, int C, int dtype, dim3 *grid) {
 
 template <typename T>
 int run_fwd(const void *x, const void *res, const float *stats, long long M, int C, Map mp, dim3 grid, int relu, void *y,
-            hipStream_t s) {
+            hipStream_t s, unsigned char *relu_mask = nullptr) {
 #define BFHIP_BN2D_APPLY(RES, RELU)                                                                             \
   hipLaunchKernelGGL((bn2d_apply_kernel<T, RES, RELU>), grid, dim3(256), 0, s, (const T *)x, (const T *)res, \
-                     stats, M, C, mp, (T *)y)
+                     stats, M, C, mp, (T *)y, (RES && RELU) ? relu_mask : (unsigned char *)nullptr)
   if (res) { if (relu) BFHIP_BN2D_APPLY(true, true); else BFHIP_BN2D_APPLY(true, false); }
   else { if (relu) BFHIP_BN2D_APPLY(false, true); else BFHIP_BN2D_APPLY(false, false); }
 #undef BFHIP_BN2D_APPLY
@@ -623,11 +638,12 @@ BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float
   return check_launch("bn2d_fwd");
 }
 
-BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta,
-                                         long long M, int C, int dtype, float eps, float momentum, int relu,
-                                         float *running_mean, float *running_var, float *stats, void *y,
-                                         const float *partial, int nblk, const int32_t *m_dev, void *stream_) {
+static int bn2d_fwd_partials_impl(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
+                                  int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
+                                  float *stats, void *y, const float *partial, int nblk, const int32_t *m_dev,
+                                  unsigned char *relu_mask, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  BFHIP_REQUIRE(!relu_mask || (dtype == 1 && relu && residual), "bn2d_fwd_partials: a ReLU bit mask needs bf16 + residual + ReLU");
   BFHIP_REQUIRE(bfhip_bn2d_supported(M, C, dtype), "bn2d_fwd_partials: unsupported shape M=%lld C=%d dtype=%d", M, C, dtype);
   BFHIP_REQUIRE(x && gamma && beta && stats && y && partial && nblk > 0, "bn2d_fwd_partials: null pointer");
   BFHIP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0,
@@ -638,16 +654,38 @@ BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, co
   ProfScope ps;
   prof_begin(BFHIP_OP_BN2D_FWD, s, &ps);
   hipLaunchKernelGGL(bn2d_finalize_kernel<FwdFin>, dim3(ceil_div(C, 8)), dim3(kFinThreads), 0, s, partial, nblk, fin);
-  if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s);
+  if (dtype == 1) run_fwd<bf16_t>(x, residual, stats, M, C, mp, grid, relu, y, s, relu_mask);
   else run_fwd<float>(x, residual, stats, M, C, mp, grid, relu, y, s);
   prof_end(&ps);
   return check_launch("bn2d_fwd_partials");
 }
 
-BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma,
-                                long long M, int C, int dtype, int relu, void *dx, void *dres, float *dgb,
-                                const int32_t *m_dev, void *workspace, size_t workspace_bytes, void *stream_) {
+BFHIP_EXPORT int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta,
+                                         long long M, int C, int dtype, float eps, float momentum, int relu,
+                                         float *running_mean, float *running_var, float *stats, void *y,
+                                         const float *partial, int nblk, const int32_t *m_dev, void *stream_) {
+  return bn2d_fwd_partials_impl(x, residual, gamma, beta, M, C, dtype, eps, momentum, relu, running_mean, running_var, stats, y,
+                                partial, nblk, m_dev, nullptr, stream_);
+}
+
+// ... and the ReLU decision of every element as one bit (relu_mask u8[M][C / 8]; bf16, residual + ReLU only): the backward
+// (bfhip_bn2d_bwd_mask) reads the bits instead of the saved output
+BFHIP_EXPORT int bfhip_bn2d_fwd_partials_mask(const void *x, const void *residual, const float *gamma, const float *beta,
+                                              long long M, int C, int dtype, float eps, float momentum, int relu,
+                                              float *running_mean, float *running_var, float *stats, void *y,
+                                              const float *partial, int nblk, const int32_t *m_dev, unsigned char *relu_mask,
+                                              void *stream_) {
+  BFHIP_REQUIRE(relu_mask, "bn2d_fwd_partials_mask: null mask");
+  return bn2d_fwd_partials_impl(x, residual, gamma, beta, M, C, dtype, eps, momentum, relu, running_mean, running_var, stats, y,
+                                partial, nblk, m_dev, relu_mask, stream_);
+}
+
+static int bn2d_bwd_impl(const void *dy, const void *x, const void *y, const unsigned char *relu_mask, const float *stats,
+                         const float *gamma, long long M, int C, int dtype, int relu, void *dx, void *dres, float *dgb,
+                         const int32_t *m_dev, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  BFHIP_REQUIRE(!relu_mask || (dtype == 1 && relu), "bn2d_bwd: a ReLU bit mask needs bf16 + ReLU");
+  if (relu_mask) y = relu_mask;  // the kernels' MASK == 3 mode reads the bits through the y pointer
   BFHIP_REQUIRE(bfhip_bn2d_supported(M, C, dtype), "bn2d_bwd: unsupported shape M=%lld C=%d dtype=%d", M, C, dtype);
   BFHIP_REQUIRE(dy && x && stats && gamma && dx && dgb, "bn2d_bwd: null pointer");
   BFHIP_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
@@ -661,13 +699,14 @@ BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, co
   Tree tr{cnt, pl.gp, pl.nblk, pl.ng};
   BwdFin fin{M, m_dev, C, stats, dgb, pl.coef};
   // ReLU mask: from the saved output when one is given (residual layers), otherwise recomputed from x
-  const int mask = !relu ? 0 : (y ? 2 : 1);
+  const int mask = !relu ? 0 : (relu_mask ? 3 : (y ? 2 : 1));
   ProfScope ps;
   prof_begin(BFHIP_OP_BN2D_BWD, s, &ps);
 #define BFHIP_BN2D_BWD(T, MASK) run_bwd<T, MASK>(dy, x, y, stats, M, C, pl.mp, pl.grid, pl.partial, pl.coef, tr, fin, dx, dres, s)
   if (dtype == 1) {
     if (mask == 0) BFHIP_BN2D_BWD(bf16_t, 0);
     else if (mask == 1) BFHIP_BN2D_BWD(bf16_t, 1);
+    else if (mask == 3) BFHIP_BN2D_BWD(bf16_t, 3);
     else BFHIP_BN2D_BWD(bf16_t, 2);
   } else {
     if (mask == 0) BFHIP_BN2D_BWD(float, 0);
@@ -677,4 +716,20 @@ BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, co
 #undef BFHIP_BN2D_BWD
   prof_end(&ps);
   return check_launch("bn2d_bwd");
+}
+
+BFHIP_EXPORT int bfhip_bn2d_bwd(const void *dy, const void *x, const void *y, const float *stats, const float *gamma,
+                                long long M, int C, int dtype, int relu, void *dx, void *dres, float *dgb,
+                                const int32_t *m_dev, void *workspace, size_t workspace_bytes, void *stream_) {
+  return bn2d_bwd_impl(dy, x, y, nullptr, stats, gamma, M, C, dtype, relu, dx, dres, dgb, m_dev, workspace, workspace_bytes, stream_);
+}
+
+// the backward of a bf16 residual + ReLU layer from the forward's bit mask (bfhip_bn2d_fwd_partials_mask) instead of the saved
+// output: 1/16 of the bytes, in both of its passes
+BFHIP_EXPORT int bfhip_bn2d_bwd_mask(const void *dy, const void *x, const unsigned char *relu_mask, const float *stats,
+                                     const float *gamma, long long M, int C, int dtype, void *dx, void *dres, float *dgb,
+                                     const int32_t *m_dev, void *workspace, size_t workspace_bytes, void *stream_) {
+  BFHIP_REQUIRE(relu_mask, "bn2d_bwd_mask: null mask");
+  return bn2d_bwd_impl(dy, x, nullptr, relu_mask, stats, gamma, M, C, dtype, 1, dx, dres, dgb, m_dev, workspace, workspace_bytes,
+                       stream_);
 }

@@ -522,6 +522,15 @@ int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw
 int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
                             int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
                             float *stats, void *y, const float *partial, int nblk, const int32_t *m_dev, void *stream);
+/* The same, also storing the ReLU decision of every element as one bit (relu_mask u8[M][C/8]; bf16 with residual and ReLU only),
+ * and the backward that reads those bits instead of the saved output y (1/16 of its bytes, in both passes of the backward). */
+int bfhip_bn2d_fwd_partials_mask(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
+                                 int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,
+                                 float *stats, void *y, const float *partial, int nblk, const int32_t *m_dev,
+                                 unsigned char *relu_mask, void *stream);
+int bfhip_bn2d_bwd_mask(const void *dy, const void *x, const unsigned char *relu_mask, const float *stats, const float *gamma,
+                        long long M, int C, int dtype, void *dx, void *dres, float *dgb, const int32_t *m_dev, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * gradient clipping + AdamW + bf16 parameter refresh of all parameter tensors in three launches

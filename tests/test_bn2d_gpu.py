@@ -197,3 +197,37 @@ torch.save(out, sys.argv[1])
     for a, b in zip(res["0"], res["1"]):
         # same partial sums, same fixed-order fp64 combine up to the grouping of the tree: last-bit differences only
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_residual_relu_backward_from_the_bit_mask_equals_backward_from_saved_output(dev, monkeypatch):
+    """Bottleneck tail (conv3 -> BN + identity + ReLU): with the statistics handed over by the HIP convolution the forward stores
+    the ReLU decision of every element as one bit and the backward reads the bits instead of the saved output
+    (bfhip_bn2d_fwd_partials_mask / bfhip_bn2d_bwd_mask).  Output, input gradient, residual gradient and parameter gradients
+    must equal the saved-output path bit for bit (odd row count, a channel count with a partial column tile)."""
+    from bevfusion_amd import bn2d as b2
+    from bevfusion_amd.conv2d import conv2d
+    torch.manual_seed(11)
+    N, Cin, C, H, W = 3, 64, 264, 17, 23
+    x_in = torch.randn(N, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, Cin, 1, 1, device=dev) / 8).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ident = torch.randn(N, C, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, C, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for bits in (True, False):
+        monkeypatch.setattr(b2, "RELU_BITS", bits)
+        torch.manual_seed(12)   # the same BatchNorm parameters in both passes
+        bn = b2.BatchNorm2dAct(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+            bn.weight.copy_(bn.weight.to(torch.bfloat16).float())
+        xi, idn = x_in.clone().requires_grad_(True), ident.clone().requires_grad_(True)
+        y, partial = conv2d(xi, w, None, 1, 0, 1, True)
+        y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
+        out = bn(y, residual=idn, relu=True)
+        saved = [t for t in out.grad_fn.saved_tensors if t is not None]
+        assert any(t.dtype == torch.uint8 for t in saved) == bits
+        out.backward(gy)
+        res[bits] = (out.detach(), xi.grad, idn.grad, bn.weight.grad, bn.bias.grad)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
