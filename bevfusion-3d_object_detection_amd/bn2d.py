@@ -24,8 +24,9 @@ _WS = {}
 def _apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial=None, rows_dev=None):
     """rows_dev (optional int32[1] device tensor): number of ACTIVE rows of a capacity-sized matrix (the rest are zeros)."""
     ext = _lib.torch_ext()
-    if ext is not None and partial is None and rows_dev is None:  # C++ autograd front-end: ~3x less host time per call
-        return ext.bn2d(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu)
+    if (ext is not None and rows_dev is None and weight.dtype == torch.float32
+            and (partial is None or partial.dtype == torch.float32)):  # C++ autograd front-end: ~3x less host time per call
+        return ext.bn2d(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial, RELU_BITS)
     return _BN2dFunction.apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial, rows_dev)
 
 

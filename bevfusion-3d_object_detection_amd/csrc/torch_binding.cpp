@@ -28,7 +28,7 @@ class BN2dFn : public torch::autograd::Function<BN2dFn> {
  public:
   static Tensor forward(AutogradContext *ctx, const Tensor &x, const c10::optional<Tensor> &residual, const Tensor &weight,
                         const Tensor &bias, const Tensor &running_mean, const Tensor &running_var, double eps,
-                        double momentum, bool relu) {
+                        double momentum, bool relu, const c10::optional<Tensor> &partial, bool relu_bits) {
     const int64_t C = x.size(1), M = x.numel() / C;
     const int dt = dt_code(x);
     Tensor res;
@@ -38,15 +38,35 @@ class BN2dFn : public torch::autograd::Function<BN2dFn> {
     }
     Tensor y = at::empty_like(x);
     Tensor stats = at::empty({4 * C}, x.options().dtype(at::kFloat));
-    const size_t wsb = bfhip_bn2d_workspace_bytes(M, (int)C, dt);
-    Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
-    check(bfhip_bn2d_fwd(x.data_ptr(), res.defined() ? res.data_ptr() : nullptr, weight.data_ptr<float>(),
-                         bias.data_ptr<float>(), M, (int)C, dt, (float)eps, (float)momentum, relu ? 1 : 0,
-                         running_mean.data_ptr<float>(), running_var.data_ptr<float>(), stats.data_ptr<float>(), y.data_ptr(),
-                         nullptr, ws.data_ptr(), wsb, cur_stream(x)),
-          "bn2d_fwd");
-    const bool keep_y = relu && res.defined();  // otherwise the ReLU mask is recomputed from x
-    ctx->save_for_backward({x, keep_y ? y : Tensor(), stats, weight});
+    Tensor mask;  // residual + ReLU behind a HIP conv: one bit per element for the backward instead of the saved output
+    if (partial.has_value() && partial->defined()) {
+      // the producing convolution accumulated the column sums in its epilogue: no statistics pass
+      const Tensor &pt = *partial;
+      if (relu_bits && relu && res.defined() && dt == 1 && C % 8 == 0) {
+        mask = at::empty({M, C / 8}, x.options().dtype(at::kByte));
+        check(bfhip_bn2d_fwd_partials_mask(x.data_ptr(), res.data_ptr(), weight.data_ptr<float>(), bias.data_ptr<float>(), M, (int)C, dt,
+                                           (float)eps, (float)momentum, 1, running_mean.data_ptr<float>(),
+                                           running_var.data_ptr<float>(), stats.data_ptr<float>(), y.data_ptr(),
+                                           pt.data_ptr<float>(), (int)pt.size(0), nullptr, mask.data_ptr<uint8_t>(), cur_stream(x)),
+              "bn2d_fwd_partials_mask");
+      } else {
+        check(bfhip_bn2d_fwd_partials(x.data_ptr(), res.defined() ? res.data_ptr() : nullptr, weight.data_ptr<float>(),
+                                      bias.data_ptr<float>(), M, (int)C, dt, (float)eps, (float)momentum, relu ? 1 : 0,
+                                      running_mean.data_ptr<float>(), running_var.data_ptr<float>(), stats.data_ptr<float>(),
+                                      y.data_ptr(), pt.data_ptr<float>(), (int)pt.size(0), nullptr, cur_stream(x)),
+              "bn2d_fwd_partials");
+      }
+    } else {
+      const size_t wsb = bfhip_bn2d_workspace_bytes(M, (int)C, dt);
+      Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+      check(bfhip_bn2d_fwd(x.data_ptr(), res.defined() ? res.data_ptr() : nullptr, weight.data_ptr<float>(),
+                           bias.data_ptr<float>(), M, (int)C, dt, (float)eps, (float)momentum, relu ? 1 : 0,
+                           running_mean.data_ptr<float>(), running_var.data_ptr<float>(), stats.data_ptr<float>(), y.data_ptr(),
+                           nullptr, ws.data_ptr(), wsb, cur_stream(x)),
+            "bn2d_fwd");
+    }
+    const bool keep_y = relu && res.defined() && !mask.defined();  // otherwise the ReLU mask is recomputed from x / read from the bits
+    ctx->save_for_backward({x, keep_y ? y : Tensor(), stats, weight, mask});
     ctx->saved_data["relu"] = relu;
     ctx->saved_data["has_res"] = res.defined();
     if (res.defined()) ctx->saved_data["res_dtype"] = (int64_t)residual->scalar_type();
@@ -55,7 +75,7 @@ class BN2dFn : public torch::autograd::Function<BN2dFn> {
 
   static tensor_list backward(AutogradContext *ctx, tensor_list grads) {
     auto saved = ctx->get_saved_variables();
-    const Tensor &x = saved[0], &y = saved[1], &stats = saved[2], &weight = saved[3];
+    const Tensor &x = saved[0], &y = saved[1], &stats = saved[2], &weight = saved[3], &mask = saved[4];
     const bool relu = ctx->saved_data["relu"].toBool(), has_res = ctx->saved_data["has_res"].toBool();
     const int64_t C = x.size(1), M = x.numel() / C;
     const int dt = dt_code(x);
@@ -67,21 +87,28 @@ class BN2dFn : public torch::autograd::Function<BN2dFn> {
     Tensor dgb = at::empty({2 * C}, x.options().dtype(at::kFloat));
     const size_t wsb = bfhip_bn2d_workspace_bytes(M, (int)C, dt);
     Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
-    check(bfhip_bn2d_bwd(dy.data_ptr(), x.data_ptr(), y.defined() ? y.data_ptr() : nullptr, stats.data_ptr<float>(),
-                         weight.data_ptr<float>(), M, (int)C, dt, relu ? 1 : 0, dx.data_ptr(),
-                         dres.defined() ? dres.data_ptr() : nullptr, dgb.data_ptr<float>(), nullptr, ws.data_ptr(), wsb, cur_stream(x)),
-          "bn2d_bwd");
+    if (mask.defined())
+      check(bfhip_bn2d_bwd_mask(dy.data_ptr(), x.data_ptr(), mask.data_ptr<uint8_t>(), stats.data_ptr<float>(),
+                                weight.data_ptr<float>(), M, (int)C, dt, dx.data_ptr(), dres.defined() ? dres.data_ptr() : nullptr,
+                                dgb.data_ptr<float>(), nullptr, ws.data_ptr(), wsb, cur_stream(x)),
+            "bn2d_bwd_mask");
+    else
+      check(bfhip_bn2d_bwd(dy.data_ptr(), x.data_ptr(), y.defined() ? y.data_ptr() : nullptr, stats.data_ptr<float>(),
+                           weight.data_ptr<float>(), M, (int)C, dt, relu ? 1 : 0, dx.data_ptr(),
+                           dres.defined() ? dres.data_ptr() : nullptr, dgb.data_ptr<float>(), nullptr, ws.data_ptr(), wsb, cur_stream(x)),
+            "bn2d_bwd");
     if (has_res) {
       auto rdt = (at::ScalarType)ctx->saved_data["res_dtype"].toInt();
       if (rdt != dres.scalar_type()) dres = dres.to(rdt);
     }
-    return {dx, dres, dgb.slice(0, 0, C), dgb.slice(0, C, 2 * C), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {dx, dres, dgb.slice(0, 0, C), dgb.slice(0, C, 2 * C), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
 Tensor bn2d(const Tensor &x, const c10::optional<Tensor> &residual, const Tensor &weight, const Tensor &bias,
-            const Tensor &running_mean, const Tensor &running_var, double eps, double momentum, bool relu) {
-  return BN2dFn::apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu);
+            const Tensor &running_mean, const Tensor &running_var, double eps, double momentum, bool relu,
+            const c10::optional<Tensor> &partial, bool relu_bits) {
+  return BN2dFn::apply(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu, partial, relu_bits);
 }
 
 // y = act(BN_train(x) [+ residual]) on sparse feature matrices f32[N, C]  (csrc/bn1d.hip)
@@ -138,7 +165,10 @@ Tensor bn1d(const Tensor &x, const c10::optional<Tensor> &residual, const Tensor
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd front-ends over libbevfusion_hip.so (include/bevfusion_hip.h)";
-  m.def("bn2d", &bn2d, "fused BatchNorm2d(+residual)(+ReLU), channels-last, training mode");
+  m.def("bn2d", &bn2d, "fused BatchNorm2d(+residual)(+ReLU), channels-last, training mode; optional statistics partials of the producing conv",
+        pybind11::arg("x"), pybind11::arg("residual"), pybind11::arg("weight"), pybind11::arg("bias"), pybind11::arg("running_mean"),
+        pybind11::arg("running_var"), pybind11::arg("eps"), pybind11::arg("momentum"), pybind11::arg("relu"),
+        pybind11::arg("partial") = c10::optional<Tensor>(), pybind11::arg("relu_bits") = false);
   m.def("bn1d", &bn1d, "fused BatchNorm1d(+residual)(+ReLU) on f32[N, C], training mode");
   m.def("abi_version", []() { return bfhip_abi_version(); });
 }
