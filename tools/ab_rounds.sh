@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B of the step time against the previous round's tree on ONE box (boxes differ by up to 10 %): `_r02/` is a git worktree of the
-# round-2 head with its own built .so (git-ignored; `git worktree add -f _r02 <commit>`), runs alternate old / new.
+# A/B of the step time against another tree on ONE box (boxes differ by up to 10 %): `_r02/` is a git worktree of the commit to
+# compare with, with its own built .so (`git worktree add -f _r02 <commit> && (cd _r02 && python bevfusion-3d_object_detection_amd/_build.py)`;
+# add `_r02/` to .gitignore while it exists; `git worktree remove --force _r02` afterwards), runs alternate old / new.
 #   bash tools/ab_rounds.sh [N pairs] [extra bench args]
 set -u
 n=${1:-2}; shift || true
