@@ -371,9 +371,9 @@ class PositionEncodingLearned(nn.Module):
         """xyz [B, N, in] -> [B, N, C]."""
         conv1, bn, _, conv2 = self.position_embedding_head
         B, N, _ = xyz.shape
-        h = linear_rows(xyz.reshape(B * N, -1), conv1.weight[:, :, 0], conv1.bias)
+        h = linear_rows(xyz.reshape(B * N, -1), conv1.weight.squeeze(-1), conv1.bias)
         h = bn(h.contiguous(), relu=True)
-        h = linear_rows(h, conv2.weight[:, :, 0], conv2.bias)
+        h = linear_rows(h, conv2.weight.squeeze(-1), conv2.bias)
         return h.view(B, N, -1)
 
     def forward(self, xyz):
@@ -398,12 +398,14 @@ class _MHA(nn.Module):
         q = query if query_pos is None else query + query_pos
         k = key if key_pos is None else key + key_pos
         E, H = self.embed_dims, self.num_heads
-        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        # the three projection blocks as unbind() views of the packed parameter: their gradients come back through ONE stack
+        # (slices w[i*E:(i+1)*E] cost a zero-filled [3E, E] tensor, a copy and an add per block in the backward)
+        ws = self.attn.in_proj_weight.view(3, E, E).unbind(0)
+        bs = self.attn.in_proj_bias.view(3, E).unbind(0) if self.attn.in_proj_bias is not None else (None, None, None)
         B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
 
         def proj(t, i):
-            bi = b[i * E:(i + 1) * E] if b is not None else None
-            return linear_rows(t.reshape(-1, E), w[i * E:(i + 1) * E], bi).view(B, -1, E)  # [B, L, H*d]
+            return linear_rows(t.reshape(-1, E), ws[i], bs[i]).view(B, -1, E)  # [B, L, H*d]
 
         qp, kp, vp = proj(q, 0), proj(k, 1), proj(value, 2)
         p_drop = self.attn.dropout if self.training else 0.0
@@ -475,13 +477,13 @@ class SeparateHead(nn.Module):
             h = rows
             for m in getattr(self, head):
                 if isinstance(m, ConvModule):
-                    h = F.linear(h, m.conv.weight[:, :, 0], m.conv.bias)
+                    h = F.linear(h, m.conv.weight.squeeze(-1), m.conv.bias)
                     if m.bn is not None:
                         h = m.bn(h, relu=m.act)
                     elif m.act:
                         h = F.relu(h)
                 else:
-                    h = F.linear(h, m.weight[:, :, 0], m.bias)
+                    h = F.linear(h, m.weight.squeeze(-1), m.bias)
             out[head] = h.view(B, L, -1).transpose(1, 2)
         return out
 
@@ -551,7 +553,7 @@ class BEVFusionHead(nn.Module):
         one_hot = F.one_hot(top_class, num_classes=self.num_classes)   # [B, P, classes]
         if _HEAD_ROWS and query_feat.is_cuda and self.class_encoding.kernel_size == (1,):
             # the k = 1 Conv1d over [B, classes, P] is a GEMM over the rows [B, P, classes]
-            enc = F.linear(one_hot.to(query_feat.dtype), self.class_encoding.weight[:, :, 0], self.class_encoding.bias)
+            enc = F.linear(one_hot.to(query_feat.dtype), self.class_encoding.weight.squeeze(-1), self.class_encoding.bias)
             query_feat = query_feat + enc.permute(0, 2, 1)
         else:
             query_feat = query_feat + self.class_encoding(one_hot.permute(0, 2, 1).to(query_feat.dtype))
