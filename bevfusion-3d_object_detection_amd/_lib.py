@@ -73,6 +73,7 @@ SIGNATURES = {
                                           _c_int, _c_int, _c_vp, _c_vp]),
     "bfhip_bn2d_supported": (_c_int, [ctypes.c_longlong, _c_int, _c_int]),
     "bfhip_bn2d_workspace_bytes": (_c_sz, [ctypes.c_longlong, _c_int, _c_int]),
+    "bfhip_colsum": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_bn2d_fwd": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +
                        [_c_vp] * 5 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_bn2d_bwd": (_c_int, [_c_vp] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_int] + [_c_vp] * 4 + [_c_vp, _c_sz, _c_vp]),

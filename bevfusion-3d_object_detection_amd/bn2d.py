@@ -51,6 +51,23 @@ def _workspace(device, nbytes, stream):
     return buf
 
 
+COLSUM = os.environ.get("BFHIP_COLSUM", "1") == "1"
+
+
+def colsum(t):
+    """f32[C] = sum over the rows of a dense row-major [M, C] matrix (f32 | bf16): bias gradients (sum of dy over pixels / rows) on
+    the BatchNorm statistics kernel; torch's reduction elsewhere (CPU, small or unsupported shapes)."""
+    M, C = t.shape
+    if (COLSUM and t.is_cuda and t.dtype in _DT and t.is_contiguous() and M >= 4096 and t.data_ptr() % 16 == 0
+            and _ws_bytes(M, C, _DT[t.dtype]) > 0):
+        out = torch.empty(C, dtype=torch.float32, device=t.device)
+        stream = _lib.stream_of(t)
+        ws = _workspace(t.device, _ws_bytes(M, C, _DT[t.dtype]), stream)
+        _lib.call("bfhip_colsum", t.data_ptr(), M, C, _DT[t.dtype], out.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        return out
+    return t.sum(0, dtype=torch.float32)
+
+
 class _BN2dFunction(torch.autograd.Function):
     """y = act(BN_train(x) [+ residual]); x, residual, y channels-last [N, C, H, W], f32 or bf16."""
 

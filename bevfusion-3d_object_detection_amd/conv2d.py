@@ -190,9 +190,9 @@ class _Conv2dFunction(torch.autograd.Function):
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
             if side is not None:  # a leaf like dW: behind the weight gradient on the side stream (dy is kept alive by _KEEP)
                 with torch.cuda.stream(side):
-                    db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
+                    db = _bias_grad(dy).to(ctx.bias_dtype)
             else:
-                db = dy.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
+                db = _bias_grad(dy).to(ctx.bias_dtype)
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -204,6 +204,15 @@ def _add_grad(dx, addend, fork):
         dx[:, :, ::2, ::2] += addend
         return dx
     return dx + addend
+
+
+def _bias_grad(dy):
+    """f32[C] = sum of dy [N, C, H, W] over batch and pixels; a dense channels-last dy is a row-major [N*H*W, C] matrix."""
+    N, C, H, W = dy.shape
+    if _nhwc_view(dy) == C:
+        from .bn2d import colsum
+        return colsum(dy.permute(0, 2, 3, 1).reshape(N * H * W, C))
+    return dy.sum(dim=(0, 2, 3), dtype=torch.float32)
 
 
 def _hip_dgrad(dy, x, weight, stride, pad, dil, addend=None, addend_stride=1):

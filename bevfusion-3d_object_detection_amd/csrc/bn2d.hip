@@ -212,6 +212,13 @@ struct BwdFin {
   }
 };
 
+// out[c] = column sum (the bias gradient of a convolution / linear layer: sum of dy over all pixels / rows)
+struct SumFin {
+  int C;
+  float *out;
+  __device__ __forceinline__ void operator()(int c, double s, double) const { out[c] = (float)s; }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn2d_stats_kernel(const T *__restrict__ x, long long M, int C, Map mp,
                                                          float *__restrict__ partial, Tree tr, FwdFin fin) {
@@ -606,6 +613,26 @@ BFHIP_EXPORT size_t bfhip_bn2d_workspace_bytes(long long M, int C, int dtype) {
   if (!bfhip_bn2d_supported(M, C, dtype)) return 0;
   Plan pl;
   return plan_bytes(M, C, dtype, &pl, nullptr);
+}
+
+// out f32[C] = sum over the M rows of x [M][C] (f32 | bf16, dense): the statistics pass of the fused BatchNorm with a sum-only
+// finalisation (fixed-order, fp64 combine).  Bias gradients are this: torch's strided reduction streams at ~1.1 TB/s here.
+BFHIP_EXPORT int bfhip_colsum(const void *x, long long M, int C, int dtype, float *out, void *workspace, size_t workspace_bytes,
+                              void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  BFHIP_REQUIRE(bfhip_bn2d_supported(M, C, dtype), "colsum: unsupported shape M=%lld C=%d dtype=%d", M, C, dtype);
+  BFHIP_REQUIRE(x && out && ((uintptr_t)x % 16) == 0, "colsum: null or misaligned pointer");
+  if (!workspace || workspace_bytes < bfhip_bn2d_workspace_bytes(M, C, dtype)) { set_error("colsum: workspace too small"); return BFHIP_E_WORKSPACE; }
+  Plan pl;
+  plan_bytes(M, C, dtype, &pl, workspace);
+  Tree tr{nullptr, pl.gp, pl.nblk, pl.ng};
+  FwdFin none{};
+  if (dtype == 1)
+    hipLaunchKernelGGL(bn2d_stats_kernel<bf16_t>, pl.grid, dim3(256), 0, s, (const bf16_t *)x, M, C, pl.mp, pl.partial, tr, none);
+  else
+    hipLaunchKernelGGL(bn2d_stats_kernel<float>, pl.grid, dim3(256), 0, s, (const float *)x, M, C, pl.mp, pl.partial, tr, none);
+  hipLaunchKernelGGL(bn2d_finalize_kernel<SumFin>, dim3(ceil_div(C, 8)), dim3(kFinThreads), 0, s, pl.partial, pl.nblk, SumFin{C, out});
+  return check_launch("colsum");
 }
 
 BFHIP_EXPORT int bfhip_bn2d_fwd(const void *x, const void *residual, const float *gamma, const float *beta,

@@ -177,6 +177,10 @@ class ResNet50(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda"):
+            # dtype and layout in ONE pass over the images (autocast's cast + the library's channels-last conversion of the stem's
+            # input are three)
+            x = x.to(dtype=torch.get_autocast_dtype("cuda"), memory_format=torch.channels_last)
         x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         outs = []
         for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):

@@ -20,6 +20,7 @@ _WS = {}
 # weight-gradient kernel (bf16 MFMA, LDS-DMA ring, split over the rows) does it in about a third of the time of csrc/xty.hip's
 # fp32-MFMA kernel (K = 129 600, 128 x 128: ~30 vs 90 us).  BFHIP_XTY_CONV=0: always csrc/xty.hip.
 XTY_CONV = os.environ.get("BFHIP_XTY_CONV", "1") == "1"
+XTY_CONV_MIN_ROWS = int(os.environ.get("BFHIP_XTY_CONV_MIN_ROWS", "4096"))
 
 
 def xty(x, y):
@@ -30,7 +31,7 @@ def xty(x, y):
     N = y.shape[1]
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     stream = _lib.stream_of(x)
-    if (XTY_CONV and x.dtype == torch.bfloat16 and M % 8 == 0 and N % 8 == 0 and K >= 4096 and K * max(M, N) < (1 << 31)
+    if (XTY_CONV and x.dtype == torch.bfloat16 and M % 8 == 0 and N % 8 == 0 and K >= XTY_CONV_MIN_ROWS and K * max(M, N) < (1 << 31)
             and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and _lib.load().bfhip_conv2d_supported(1, K, 1, N, M, 1, 1, 1, 0, 1)):
         nbytes = _lib.call_size("bfhip_conv2d_wgrad_workspace_bytes", 1, K, 1, N, M, 1, 1)
         key = (x.device, stream)
@@ -72,7 +73,8 @@ class _LinearRows(torch.autograd.Function):
             xs = x if x.dtype == dy.dtype else x.to(dy.dtype)
             dw = xty(dy, xs).to(weight.dtype)           # [out, in] = dY^T X
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+            from .bn2d import colsum
+            db = colsum(dy).to(ctx.bias_dtype)
         return dx, dw, db
 
 

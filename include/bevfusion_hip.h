@@ -350,6 +350,9 @@ int bfhip_bn1d_bwd(const float *dy, const float *y, const float *x, const float 
  *   from x and y may be NULL); dgb f32[2C] <- (dgamma, dbeta); dres optional.
  * --------------------------------------------------------------------------------------- */
 int bfhip_bn2d_supported(long long M, int C, int dtype);
+/* out f32[C] = column sums of x [M][C] (dtype 0 f32 | 1 bf16, dense; shapes as bfhip_bn2d_supported, workspace as
+ * bfhip_bn2d_workspace_bytes): the bias gradient of a convolution / linear layer (sum of dy over pixels / rows), fixed order. */
+int bfhip_colsum(const void *x, long long M, int C, int dtype, float *out, void *workspace, size_t workspace_bytes, void *stream);
 size_t bfhip_bn2d_workspace_bytes(long long M, int C, int dtype);
 int bfhip_bn2d_fwd(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,
                    int dtype, float eps, float momentum, int relu, float *running_mean, float *running_var,

@@ -237,3 +237,19 @@ def test_residual_relu_backward_from_the_bit_mask_equals_backward_from_saved_out
         res[bits] = (out.detach(), xi.grad, idn.grad, bn.weight.grad, bn.bias.grad)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(129600, 128), (67584, 256), (4681, 72), (5000, 8)])
+def test_colsum_matches_torch(dev, dtype, shape):
+    """bfhip_colsum (bias gradients: sum of dy over pixels / rows) against an fp64 sum; small matrices take torch's reduction."""
+    from bevfusion_amd.bn2d import colsum
+    torch.manual_seed(shape[0])
+    t = torch.randn(shape, device=dev).to(dtype)
+    ref = t.double().sum(0)
+    got = colsum(t)
+    assert got.dtype == torch.float32 and got.shape == (shape[1],)
+    assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-3 * float(ref.abs().max()))
+    assert torch.equal(colsum(t), got)                                   # fixed summation order
+    small = t[:100].contiguous()
+    assert torch.allclose(colsum(small).double(), small.double().sum(0), rtol=1e-4, atol=1e-4)
