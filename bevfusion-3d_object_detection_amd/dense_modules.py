@@ -401,6 +401,11 @@ class _MHA(nn.Module):
     def forward(self, query, key, value, query_pos=None, key_pos=None):
         q = query if query_pos is None else query + query_pos
         k = key if key_pos is None else key + key_pos
+        return self.attend(query, q, k, value)
+
+    def attend(self, query, q, k, value):
+        """identity + dropout(attn(q, k, value)) with the position terms already added by the caller (the decoder layer feeds the
+        SAME tensor as key + key_pos and as value -- mmcv's convention -- so it adds once instead of once per role)."""
         E, H = self.embed_dims, self.num_heads
         # the three projection blocks as unbind() views of the packed parameter: their gradients come back through ONE stack
         # (slices w[i*E:(i+1)*E] cost a zero-filled [3E, E] tensor, a copy and an add per block in the backward)
@@ -444,8 +449,12 @@ class TransformerDecoderLayer(nn.Module):
         qp = self.self_posembed.forward_nlc(query_pos)
         kp = self.cross_posembed.forward_nlc(key_pos)
         q, k = query.transpose(1, 2), key.transpose(1, 2)
-        q = self.norms[0](self.self_attn(q, q, q + qp, qp, qp))
-        q = self.norms[1](self.cross_attn(q, k, k + kp, qp, kp))
+        # (reference: self_attn(q, q, q + qp, qp, qp) and cross_attn(q, k, k + kp, qp, kp) -- query, key and value of the self
+        # attention are all q + qp, key and value of the cross attention both k + kp: each sum is formed once)
+        qq = q + qp
+        q = self.norms[0](self.self_attn.attend(q, qq, qq, qq))
+        kk = k + kp
+        q = self.norms[1](self.cross_attn.attend(q, q + qp, kk, kk))
         q = self.norms[2](self.ffn(q))
         return q.transpose(1, 2)
 
@@ -476,6 +485,8 @@ class SeparateHead(nn.Module):
             return {head: getattr(self, head)(x) for head in self.heads}
         B, C, L = x.shape
         rows = x.transpose(1, 2).reshape(B * L, C)
+        if torch.is_autocast_enabled("cuda") and rows.dtype != torch.get_autocast_dtype("cuda"):
+            rows = rows.to(torch.get_autocast_dtype("cuda"))   # once, not once per head inside every F.linear
         out = {}
         for head in self.heads:
             h = rows
