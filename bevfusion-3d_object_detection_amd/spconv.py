@@ -577,7 +577,19 @@ class _BN1dFunction(torch.autograd.Function):
 
 class BatchNorm1dAct(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters / buffers / state_dict keys) whose forward can also add a residual and apply
-    ReLU; in training mode on fp32 CUDA features of a supported width it runs the fused HIP kernels."""
+    ReLU; in training mode on fp32 CUDA features of a supported width it runs the fused HIP kernels.  `num_batches_tracked`
+    is advanced lazily like bn2d._LazyBatchCounter's (a host counter flushed into the buffer when the state dict is read)."""
+
+    _pending_batches = 0
+
+    def _flush_batches(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._pending_batches)
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_batches()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def forward(self, x, residual=None, relu=False, rows_dev=None):
         """rows_dev (static capacity mode): device i32[1] count of ACTIVE rows; the rows beyond it are zeros on entry."""
@@ -586,8 +598,7 @@ class BatchNorm1dAct(nn.BatchNorm1d):
                 and self.affine and self.track_running_stats and self.momentum is not None and C % 8 == 0):
             # bf16 feature matrices: the channels-last BN kernels (csrc/bn2d.hip) on the [N, C, 1, 1] view
             from . import bn2d
-            if self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+            self._pending_batches += 1
             N = x.shape[0]
             res = residual.contiguous().view(N, C, 1, 1) if residual is not None else None
             y = bn2d._apply(x.contiguous().view(N, C, 1, 1), res, self.weight, self.bias, self.running_mean, self.running_var,
@@ -597,8 +608,7 @@ class BatchNorm1dAct(nn.BatchNorm1d):
                  and self.affine and self.track_running_stats and self.momentum is not None
                  and C % 4 == 0 and C <= 256 and 256 % C == 0)
         if fused:
-            if self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+            self._pending_batches += 1
             ext = _lib.torch_ext()
             if ext is not None and rows_dev is None:
                 return ext.bn1d(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
@@ -607,6 +617,7 @@ class BatchNorm1dAct(nn.BatchNorm1d):
                                        self.momentum, relu, rows_dev)
         if rows_dev is not None:
             raise RuntimeError("capacity-sized feature matrices need the fused BatchNorm kernels (training mode, supported width)")
+        self._flush_batches()
         out = super().forward(x)
         if residual is not None:
             out = out + residual
