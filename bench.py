@@ -56,6 +56,7 @@ DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd
 # `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side streams off
 # (one queue, nothing beside them) -- the number a rocprofv3 kernel trace reproduces.
 HOST_SLEEP_US = int(os.environ.get("BENCH_HOST_SLEEP_US", "0"))
+PREWARM_STEPS = int(os.environ.get("BENCH_PREWARM_STEPS", "6"))
 
 
 def _issue_stats(ts):
@@ -696,9 +697,16 @@ def main():
             torch.cuda.synchronize()
 
     first_loss = None
+    # settling steps BEFORE the W warm-up steps of the contract (untimed initialisation, like building the model): the first steps of
+    # a process pick MIOpen solutions, load code objects and grow the caching allocator and the library's workspaces; with a small
+    # --warmup from the caller they would otherwise reach into the timed region.  BENCH_PREWARM_STEPS=0 switches them off.
+    for i in range(0 if cpu_mode else PREWARM_STEPS):
+        r = wl.step()
+        if first_loss is None and torch.is_tensor(r):
+            first_loss = r.detach()
     for i in range(args.warmup):
         r = wl.step()
-        if i == 0 and torch.is_tensor(r):
+        if first_loss is None and torch.is_tensor(r):
             first_loss = r.detach()
     barrier()
     graphed = bool(getattr(wl, "use_graph", False))
