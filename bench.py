@@ -50,7 +50,7 @@ GRAD_SYNC = os.environ.get("BENCH_GRAD_SYNC", "flat")
 # per training step)
 PROFILE_LEVEL = int(os.environ.get("BENCH_PROFILE_LEVEL", "2"))
 DENSE_EVERY = max(1, int(os.environ.get("BENCH_PROFILE_DENSE_EVERY", "10")))
-DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd")
+DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd", "conv2d_pw_fwd", "conv2d_pw_dgrad")
 # `full` runs on three HIP queues (camera / BEV chain; LiDAR branch; weight gradients), so an event pair around an op in the
 # timed region also measures the wait for CUs the other queues hold.  Roofline fractions are computed from
 # `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side streams off
@@ -408,12 +408,23 @@ class _ModelWorkload:
             Cout, _, KH, KW = weight.shape
             OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
             OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-            return (N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin)
+            pw = KH == 1 and KW == 1 and stride == 1 and pad == 0   # served by conv_pw_kernel (own profiler ids)
+            return (N * OH * OW, Cin * KH * KW, Cout, bool(x.requires_grad), N * H * W * Cin), pw
 
-        # every entry: (M, K, Cout, data gradient wanted, input elements, forward on HIP, data gradient on HIP)
+        # every entry: (M, K, Cout, data gradient wanted, input elements, forward on HIP, data gradient on HIP, pointwise)
         def spy_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib=False, *more):
-            convs.append(shape(x, weight, stride, pad, dil) + (True, not dgrad_lib))
+            sh, pw = shape(x, weight, stride, pad, dil)
+            convs.append(sh + (True, not dgrad_lib, pw))
             return orig_c(ctx, x, weight, bias, stride, pad, dil, emit_stats, dgrad_lib, *more)
+
+        orig_s = c2._Conv2dSplitFunction.forward
+
+        def spy_s(ctx, x, weight, bias, stride, pad, dil, emit_stats):
+            # fp32 convolution as three bf16 products: one launch per direction with 3x the channels (forward, data gradient)
+            # or 3x the batch (weight gradient) -- 3x the flops of the bf16 layer in each
+            (M, K, Cout, rg, xin), pw = shape(x, weight, stride, pad, dil)
+            convs.append((M, 3 * K, Cout, rg, 3 * xin, True, True, pw))
+            return orig_s(ctx, x, weight, bias, stride, pad, dil, emit_stats)
 
         def spy_b(x, residual, *a, **k):
             if x.is_cuda and x.dim() == 4:
@@ -422,18 +433,21 @@ class _ModelWorkload:
             return orig_b(x, residual, *a, **k)
 
         def spy_h(ctx, x, weight, stride, pad, dil, dgrad_hip=False, *more):  # library forward, HIP weight gradient (ResNet-50 trunk)
-            convs.append(shape(x, weight, stride, pad, dil) + (False, bool(dgrad_hip)))
+            sh, pw = shape(x, weight, stride, pad, dil)
+            convs.append(sh + (False, bool(dgrad_hip), pw))
             hybrid.append(1)
             return orig_h(ctx, x, weight, stride, pad, dil, dgrad_hip, *more)
 
         c2._Conv2dFunction.forward, b2._apply = staticmethod(spy_c), spy_b
         c2._LibConvHipWgradFunction.forward = staticmethod(spy_h)
+        c2._Conv2dSplitFunction.forward = staticmethod(spy_s)
         try:
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
                 self.step_model(self.inputs, None, self.gts)
         finally:
             c2._Conv2dFunction.forward, b2._apply = staticmethod(orig_c), orig_b
             c2._LibConvHipWgradFunction.forward = staticmethod(orig_h)
+            c2._Conv2dSplitFunction.forward = staticmethod(orig_s)
         work = {}
         peak, note = MFMA_PEAK_BF16
 
@@ -445,9 +459,15 @@ class _ModelWorkload:
             return dict(bound=bound, flops=fl, bytes=by, unit_peak=peak, peak_note=note, scope="%d launches per step: %s" % (len(rows), scope))
 
         if convs:
-            work["conv2d_fwd"] = conv_entry(lambda c: c[5], "implicit-GEMM / pointwise forward of the BEV, view-transform, LSS-FPN and ResNet-50 1x1 "
-                                            "convolutions (csrc/conv2d.hip)")
-            work["conv2d_dgrad"] = conv_entry(lambda c: c[3] and c[6], "weight transpose + implicit GEMM in transposed-gather mode / pointwise GEMM over dy")
+            work["conv2d_fwd"] = conv_entry(lambda c: c[5] and not c[7], "implicit-GEMM forward (conv_igemm_kernel) of the BEV, view-transform, "
+                                            "LSS-FPN and ResNet-50 3x3 convolutions")
+            work["conv2d_dgrad"] = conv_entry(lambda c: c[3] and c[6] and not c[7], "implicit GEMM in transposed-gather mode (conv_igemm_kernel)")
+            work["conv2d_pw_fwd"] = conv_entry(lambda c: c[5] and c[7], "pointwise kernel (conv_pw_kernel): 1x1 stride-1 forward, a GEMM over the "
+                                               "pixel matrix with K = 64 ... 3072")
+            work["conv2d_pw_dgrad"] = conv_entry(lambda c: c[3] and c[6] and c[7], "pointwise kernel over dy (+ the fused residual-gradient addend)")
+            for k in ("conv2d_pw_fwd", "conv2d_pw_dgrad"):
+                if not work[k]["flops"]:
+                    del work[k]
             work["conv2d_wgrad"] = conv_entry(lambda c: True, "pixel-major LDS tiles, transposing LDS reads, split pixel range + fixed-order slab sum "
                                               "(incl. the %d ResNet-50 layers whose forward stays on the library)" % len(hybrid))
         if bns:

@@ -226,7 +226,8 @@ def require_cuda(t, name):
 
 OPS = dict(bev_pool_fwd=0, bev_pool_bwd=1, hard_voxelize=2, dynamic_voxelize=3, lift_splat_fwd=4, lift_splat_bwd=5,
            spconv_fwd=6, spconv_bwd=7, rulebook=8, bev_aux=9, scatter_fwd=10, scatter_bwd=11, spconv_wgrad=12, raster=13,
-           spconv_wgrad_main=14, conv2d_fwd=15, conv2d_dgrad=16, conv2d_wgrad=17, bn2d_fwd=18, bn2d_bwd=19)
+           spconv_wgrad_main=14, conv2d_fwd=15, conv2d_dgrad=16, conv2d_wgrad=17, bn2d_fwd=18, bn2d_bwd=19,
+           conv2d_pw_fwd=20, conv2d_pw_dgrad=21)
 
 
 def profile_enable(on=True):

@@ -1216,6 +1216,13 @@ BFHIP_EXPORT int bfhip_conv2d_stat_rows(int N, int OH, int OW) { return ceil_div
 
 static bool pointwise_geom(const ConvGeom &g) { return g.KH == 1 && g.KW == 1 && g.stride == 1 && g.pad == 0 && g.transposed != 2; }
 
+// largest channel count of the gathered tensor the pointwise kernel takes (BFHIP_CONV_PW_MAXC; 0 = never)
+static int pw_max_channels() {
+  static const int v = [] { const char *e = getenv("BFHIP_CONV_PW_MAXC"); return e ? atoi(e) : 4096; }();
+  return v;
+}
+static bool takes_pointwise(const ConvGeom &g) { return pointwise_geom(g) && g.C <= pw_max_channels(); }
+
 static int launch_igemm(const void *x, const void *wt, const float *bias, void *y, float *stat_partial, ConvGeom g, int out_f32,
                         hipStream_t s, const char *what, Addend add = Addend{nullptr, 0, 0, 0, 0}) {
   // tile shapes (see conv_igemm_kernel): 0 = 128 x 64, 1 = 128 x 128, 2 = 256 x 256 (bf16 output, wide GEMMs with at least
@@ -1226,7 +1233,7 @@ static int launch_igemm(const void *x, const void *wt, const float *bias, void *
   static const int tile256_min = [] { const char *e = getenv("BFHIP_CONV_TILE256_MIN"); return e ? atoi(e) : 384; }();
   // 1x1, stride 1, no padding (forward, or the data gradient of such a layer: both are plain GEMMs over the pixel matrix)
   // with a short K: conv_pw_kernel.  BFHIP_CONV_PW_MAXC: largest channel count of the gathered tensor it takes (0 = never)
-  static const int pw_maxc = [] { const char *e = getenv("BFHIP_CONV_PW_MAXC"); return e ? atoi(e) : 4096; }();
+  const int pw_maxc = pw_max_channels();
   BFHIP_REQUIRE(!add.p || (pointwise_geom(g) && g.C <= pw_maxc && !out_f32),
                 "%s: an addend is only fused into the pointwise kernel (1x1, stride 1, no padding, bf16 output)", what);
   if (pointwise_geom(g) && g.C <= pw_maxc) {
@@ -1342,7 +1349,7 @@ BFHIP_EXPORT int bfhip_conv2d_fwd(const void *x, int ldx, const void *w, const f
   g.Kout = Cout; g.ldw = KH * KW * Cin; g.ldy = ldy;
   BFHIP_REQUIRE((long long)N * H * W * ldx < (1LL << 31), "conv2d_fwd: tensors of 2^31 elements or more are not supported");
   ProfScope ps;
-  prof_begin(BFHIP_OP_CONV2D_FWD, (hipStream_t)stream_, &ps);
+  prof_begin(takes_pointwise(g) ? BFHIP_OP_CONV2D_PW_FWD : BFHIP_OP_CONV2D_FWD, (hipStream_t)stream_, &ps);
   const int rc = launch_igemm(x, w, bias, y, stat_partial, g, out_f32, (hipStream_t)stream_, "conv2d_fwd");
   prof_end(&ps);
   return rc;
@@ -1365,7 +1372,8 @@ static int conv2d_dgrad_impl(const void *dy, int ldg, const void *w, void *dx, i
                 "conv2d_dgrad: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
   const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   ProfScope ps;
-  prof_begin(BFHIP_OP_CONV2D_DGRAD, s, &ps);
+  prof_begin(KH == 1 && KW == 1 && stride == 1 && pad == 0 && Cout <= pw_max_channels() ? BFHIP_OP_CONV2D_PW_DGRAD : BFHIP_OP_CONV2D_DGRAD, s,
+             &ps);
   if (w)
     hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW), dim3(256), 0, s,
                        (const bf16_t *)w, (bf16_t *)workspace, Cout, KH * KW, Cin);

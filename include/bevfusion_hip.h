@@ -60,6 +60,8 @@ extern "C" {
 #define BFHIP_OP_CONV2D_WGRAD 17 /* bfhip_conv2d_wgrad: main kernel + slab reduce */
 #define BFHIP_OP_BN2D_FWD 18     /* bfhip_bn2d_fwd / _fwd_partials: statistics, finalize, apply */
 #define BFHIP_OP_BN2D_BWD 19     /* bfhip_bn2d_bwd: reduce, finalize, apply */
+#define BFHIP_OP_CONV2D_PW_FWD 20   /* bfhip_conv2d_fwd calls served by the pointwise kernel (1x1, stride 1): HBM-bound GEMMs over the pixel matrix */
+#define BFHIP_OP_CONV2D_PW_DGRAD 21 /* bfhip_conv2d_dgrad(_wt) calls served by the pointwise kernel */
 #define BFHIP_OP_COUNT 24
 
 int bfhip_abi_version(void);

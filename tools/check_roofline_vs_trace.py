@@ -26,8 +26,10 @@ FAMILIES = {
                  r"merge_sort|block_sort|wrapped_merge", r"sort_rows_chunk_kernel"],
     "lift_splat_fwd": [r"lift_splat_fwd"],
     "lift_splat_bwd": [r"lift_splat_bwd"],
-    "conv2d_fwd": [r"conv_igemm_kernel<[^>]*, 0>", r"conv_pw_kernel<[^>]*, 0>"],
-    "conv2d_dgrad": [r"conv_igemm_kernel<[^>]*, [12]>", r"conv_pw_kernel<[^>]*, 1>", r"conv_weight_transpose"],
+    "conv2d_fwd": [r"conv_igemm_kernel<[^>]*, 0>"],
+    "conv2d_dgrad": [r"conv_igemm_kernel<[^>]*, [12]>", r"conv_weight_transpose_kernel"],
+    "conv2d_pw_fwd": [r"conv_pw_kernel<[^>]*, 0>"],
+    "conv2d_pw_dgrad": [r"conv_pw_kernel<[^>]*, 1>"],
     "conv2d_wgrad": [r"conv_wgrad_kernel", r"conv_wgrad_wide_kernel", r"conv_wgrad_reduce_kernel"],
     "bn2d_fwd": [r"bn2d_stats", r"bn2d_finalize_kernel<[^>]*FwdFin", r"bn2d_apply"],
     "bn2d_bwd": [r"bn2d_bwd", r"bn2d_finalize_kernel<[^>]*BwdFin"],

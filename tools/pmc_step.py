@@ -20,8 +20,10 @@ FAMILIES = [
     ("bn2d forward (stats, finalize, apply)", lambda n: "bn2d_" in n),
     # last template argument of conv_igemm_kernel = MODE: 0 forward, 1 data gradient (transposed gather), 2 data gradient of a
     # strided layer by parity classes (round 2 matched a bool that no longer exists and booked these under the forward)
-    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*, [12]>|conv_pw_kernel<[^>]*, 1>", n) is not None),
-    ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n or "conv_pw_kernel" in n),
+    ("conv2d pointwise dgrad (conv_pw)", lambda n: re.search(r"conv_pw_kernel<[^>]*, 1>", n) is not None),
+    ("conv2d pointwise forward (conv_pw)", lambda n: "conv_pw_kernel" in n),
+    ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*, [12]>", n) is not None),
+    ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n),
     ("conv2d wgrad (main kernel)", lambda n: "conv_wgrad_kernel" in n or "conv_wgrad_wide_kernel" in n),
     ("conv weight transpose", lambda n: "conv_weight_transpose" in n),
     ("bn1d", lambda n: "bn1d_" in n),
@@ -53,6 +55,7 @@ BENCH_OPS = {"spconv_wgrad": ["spconv_wgrad", "wgrad_reduce + offset counts"], "
              "conv2d_fwd": ["conv2d forward (conv_igemm)"],
              "conv2d_dgrad": ["conv2d dgrad (conv_igemm, transposed gather)", "conv weight transpose"],
              "conv2d_wgrad": ["conv2d wgrad (main kernel)"],
+             "conv2d_pw_fwd": ["conv2d pointwise forward (conv_pw)"], "conv2d_pw_dgrad": ["conv2d pointwise dgrad (conv_pw)"],
              "spconv_fwd+bwd": ["spconv_gemm (fwd + dgrad)"]}
 # 16-byte-per-lane streaming readers: FETCH_SIZE reports half their bytes on gfx950 (MI355X_MICROARCH.md) -> doubled
 STREAMING = {"bn2d_fwd", "bn2d_bwd"}
