@@ -57,6 +57,7 @@ DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd
 # (one queue, nothing beside them) -- the number a rocprofv3 kernel trace reproduces.
 HOST_SLEEP_US = int(os.environ.get("BENCH_HOST_SLEEP_US", "0"))
 PREWARM_STEPS = int(os.environ.get("BENCH_PREWARM_STEPS", "6"))
+SETTLE_MAX_S = float(os.environ.get("BENCH_SETTLE_MAX_S", "15"))
 
 
 def _issue_stats(ts):
@@ -720,10 +721,34 @@ def main():
     # settling steps BEFORE the W warm-up steps of the contract (untimed initialisation, like building the model): the first steps of
     # a process pick MIOpen solutions, load code objects and grow the caching allocator and the library's workspaces; with a small
     # --warmup from the caller they would otherwise reach into the timed region.  BENCH_PREWARM_STEPS=0 switches them off.
+    settle_steps = 0
     for i in range(0 if cpu_mode else PREWARM_STEPS):
         r = wl.step()
+        settle_steps += 1
         if first_loss is None and torch.is_tensor(r):
             first_loss = r.detach()
+    if not cpu_mode and PREWARM_STEPS > 0 and SETTLE_MAX_S > 0:
+        # ... and until the step time has settled: blocks of 10 untimed steps until a block is within 5 % of the best block seen
+        # (at least two blocks, at most SETTLE_MAX_S seconds).  The first process on a freshly provisioned box has been seen to run
+        # its first seconds at 1.3-2x the steady step time with normal per-kernel GPU times (the host is still paging the image in):
+        # `config.settle_steps` says how long this took
+        t_settle, best_blk, blocks = time.perf_counter(), None, 0
+        while dist is not None or time.perf_counter() - t_settle < SETTLE_MAX_S:
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(10):
+                wl.step()
+            torch.cuda.synchronize()
+            blk = time.perf_counter() - tb
+            settle_steps += 10
+            blocks += 1
+            if dist is not None:
+                if blocks >= 2:   # several ranks: every step holds a collective, so every rank runs the same fixed two blocks
+                    break
+                continue
+            if best_blk is not None and blocks >= 2 and blk <= 1.05 * best_blk:
+                break
+            best_blk = blk if best_blk is None else min(best_blk, blk)
     for i in range(args.warmup):
         r = wl.step()
         if first_loss is None and torch.is_tensor(r):
@@ -864,7 +889,7 @@ def main():
                       "nuScenes frames/sec (%s)" % args.workload,
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "step_issue_ms": _issue_stats(issue_t),
+            "step_issue_ms": _issue_stats(issue_t), "settle_steps": settle_steps,
             "vs_baseline": None, "dtype": "bf16" if getattr(wl, "amp", False) else "f32", "data": "synthetic",
             "config": {"workload": wl.name, "frames_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                        "points_per_frame": args.points, "frustum_rows_kept": wl.nk, "bev_intervals": wl.m,
