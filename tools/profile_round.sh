@@ -17,6 +17,7 @@ if [ "$part" = A ]; then
   BFHIP_SPCONV_SORT=0 run timeout -k 10 200 python3 bench.py --no-cpu-baseline > $O/bench_full_nosort.json 2> $O/bench_nosort.err || exit 1
 elif [ "$part" = B ]; then
   export BENCH_REFERENCE_NUMERICS=0
+  export BENCH_PREWARM_STEPS=0   # the trace tools count optimizer steps: exactly warm-up + timed + one-queue steps
   # the same command without the tracer first: its figures are what the kernel sums of the trace are held against
   run timeout -k 10 300 python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/bench_full_plain_same_box.json 2> $O/plain.err || exit 1
   run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_full -o full -- python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/bench_full_under_rocprof.json 2> $O/prof_full.err || exit 1
@@ -41,6 +42,7 @@ elif [ "$part" = D ]; then
 elif [ "$part" = C ]; then
   # hardware counters: one counter per pass, kernel trace only (the pool refuses / hangs on wider combinations)
   export BENCH_NO_WORK=1
+  export BENCH_PREWARM_STEPS=0   # counter totals are divided by the 5 steps of the run
   run timeout -k 10 170 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o fetch -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 1
   run timeout -k 10 170 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o write -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err || exit 1
   python3 tools/pmc_step.py $(find $O/pmc_f -name 'fetch_counter_collection.csv' | head -1) $(find $O/pmc_w -name 'write_counter_collection.csv' | head -1) 5 > $O/pmc_traffic.json
