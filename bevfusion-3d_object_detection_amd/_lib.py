@@ -111,6 +111,10 @@ SIGNATURES = {
     "bfhip_conv2d_weight_transpose_batched": (_c_int, [_c_vp, _c_int, ctypes.c_longlong, _c_vp]),
     "bfhip_conv2d_wgrad_workspace_bytes": (_c_sz, [_c_int] * 7),
     "bfhip_conv2d_wgrad": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 11 + [_c_vp, _c_sz, _c_vp]),
+    "bfhip_conv2d_wgrad_group_table_bytes": (_c_sz, [_c_int]),
+    "bfhip_conv2d_wgrad_groupable": (_c_int, [_c_int] * 10),
+    "bfhip_conv2d_wgrad_group_plan": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "bfhip_conv2d_wgrad_group_launch": (_c_int, [_c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_bn2d_fwd_partials": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +
                                 [_c_vp] * 4 + [_c_vp, _c_int, _c_vp, _c_vp]),
     "bfhip_bn2d_fwd_partials_mask": (_c_int, [_c_vp] * 4 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int] +

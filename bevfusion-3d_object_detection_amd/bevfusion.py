@@ -221,7 +221,9 @@ class BEVFusion(nn.Module):
         overlap = bool(has_pts and has_cam and self.lidar_side_stream and points[0].is_cuda)
         if overlap:
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=points[0].device)
+                # BFHIP_SIDE_PRIORITY: stream priority of the LiDAR side stream (lower number = higher priority; out-of-range values
+                # map to the nearest valid one): the branch has slack (6 ms of work beside 25 ms on the main queue), so it can yield
+                self._side_stream = torch.cuda.Stream(device=points[0].device, priority=int(os.environ.get("BFHIP_SIDE_PRIORITY", "0")))
             side, main = self._side_stream, torch.cuda.current_stream(points[0].device)
             entry = torch.cuda.Event()
             entry.record(main)

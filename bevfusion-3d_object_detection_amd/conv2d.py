@@ -54,11 +54,137 @@ def wgrad_join():
     _KEEP.clear()
 
 
+# Grouped weight gradients (default on, BFHIP_WGRAD_GROUPED=0 / conv2d.WGRAD_GROUPED = False: every layer launches its own):
+# inside a backward pass `_launch_wgrad` only COLLECTS (x, dy, weight) and returns no gradient; a callback queued on the autograd
+# engine runs when the pass ends (before `backward()` returns, on the caller's streams) and computes dW of all collected layers
+# with one launch per tile shape plus one slab-sum launch (csrc/conv2d.hip: conv_wgrad_group_kernel), then stores / accumulates
+# `weight.grad` itself -- what AccumulateGrad would have done.  Consequences: x and dy of every layer live until the end of the
+# pass (a few GB at batch 4 beside 288 GB of HBM); tensor hooks on a conv WEIGHT do not fire for this gradient; and
+# `torch.autograd.grad(..., weight)` finds no gradient for the weight (it raises "appears to not have been used") -- switch the
+# grouping off for such calls.  Not used while a HIP graph is being captured (the table upload is host memory of this step) or
+# with the side-stream option above.
+WGRAD_GROUPED = os.environ.get("BFHIP_WGRAD_GROUPED", "1") == "1"
+_PENDING = []      # (x, dy, weight, row of the layer table, producing stream) of the running backward pass
+_GROUPABLE = {}    # geometry -> bool
+_GROUP_STATE = {}  # device -> _WgradGroupState
+_LAYER_DT = None
+
+
+class _WgradGroupState:
+    """Per device: two pinned images of the group table (alternating: a copy may still be in flight), its device copy, the slabs."""
+
+    def __init__(self, device):
+        self.device = device
+        self.host = [None, None]
+        self.dev = None
+        self.slab = None
+        self.flip = 0
+
+    def tables(self, nbytes):
+        if self.dev is None or self.dev.numel() < nbytes:
+            cap = max(int(nbytes) * 2, 1 << 16)
+            self.host = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        self.flip ^= 1
+        return self.host[self.flip], self.dev
+
+    def slabs(self, nbytes):
+        if self.slab is None or self.slab.numel() < nbytes:
+            self.slab = None
+            self.slab = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self.slab
+
+
+def _layer_dtype():
+    global _LAYER_DT
+    if _LAYER_DT is None:
+        import numpy as np
+        _LAYER_DT = np.dtype([("x", "<u8"), ("dy", "<u8"), ("dw", "<u8")] + [(k, "<i4") for k in (
+            "ldx", "ldg", "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "dil", "dw_bf16", "reserved")])
+        assert _LAYER_DT.itemsize == 80  # include/bevfusion_hip.h: bfhip_wgrad_layer
+    return _LAYER_DT
+
+
+def _defer_wgrad(x, dy, weight, stride, pad, dil):
+    """True when the layer's weight gradient was queued for the grouped launch at the end of the running backward pass."""
+    N, Cin, H, W = x.shape
+    Cout, _, KH, KW = weight.shape
+    key = (N, H, W, Cin, Cout, KH, KW, stride, pad, dil)
+    ok = _GROUPABLE.get(key)
+    if ok is None:
+        ok = _GROUPABLE[key] = bool(_lib.load().bfhip_conv2d_wgrad_groupable(*key))
+    # only a leaf parameter without tensor hooks: the gradient of anything else (a cast copy of a master weight, a hooked tensor)
+    # has to travel on through the graph
+    if (not ok or not weight.is_leaf or weight._backward_hooks or weight.dtype not in (torch.bfloat16, torch.float32)
+            or torch.cuda.is_current_stream_capturing()):
+        return False
+    ldx, ldg = _nhwc_view(x), _nhwc_view(dy)
+    if ldx is None or ldg is None:
+        return False
+    if not _PENDING:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+        except RuntimeError:  # not inside a backward pass of the engine
+            return False
+    row = (x.data_ptr(), dy.data_ptr(), 0, ldx, ldg, N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
+           1 if weight.dtype == torch.bfloat16 else 0, 0)
+    _PENDING.append((x, dy, weight, row, _lib.stream_of(x)))
+    return True
+
+
+def _flush_wgrads():
+    """End of a backward pass: dW of every collected layer in one group per device; stores / accumulates weight.grad."""
+    import ctypes
+
+    import numpy as np
+    pend = _PENDING[:]
+    _PENDING.clear()
+    if not pend:
+        return
+    by_dev = {}
+    for e in pend:
+        by_dev.setdefault(e[0].device, []).append(e)
+    lib = _lib.load()
+    with torch.no_grad():
+        for dev, entries in by_dev.items():
+            st = _GROUP_STATE.get(dev)
+            if st is None:
+                st = _GROUP_STATE[dev] = _WgradGroupState(dev)
+            cur = torch.cuda.current_stream(dev)
+            raw = cur.cuda_stream
+            n = len(entries)
+            dws = []
+            for x, dy, weight, row, s in entries:
+                if s != raw:  # produced on another stream than the one the group runs on (the engine has already joined them)
+                    x.record_stream(cur)
+                    dy.record_stream(cur)
+                Cout, Cin, KH, KW = weight.shape
+                dws.append(torch.empty((Cout, KH, KW, Cin), dtype=weight.dtype, device=dev).permute(0, 3, 1, 2))
+            layers = np.array([e[3] for e in entries], dtype=_layer_dtype())
+            layers["dw"] = [d.data_ptr() for d in dws]
+            nbytes = int(lib.bfhip_conv2d_wgrad_group_table_bytes(n))
+            host, table = st.tables(nbytes)
+            slab_bytes = ctypes.c_size_t(0)
+            _lib.call("bfhip_conv2d_wgrad_group_plan", layers.ctypes.data, n, 0, host.data_ptr(), nbytes, ctypes.byref(slab_bytes))
+            slab = st.slabs(slab_bytes.value)
+            with torch.cuda.device(dev):
+                table[:nbytes].copy_(host[:nbytes], non_blocking=True)
+                _lib.call("bfhip_conv2d_wgrad_group_launch", host.data_ptr(), table.data_ptr(), slab.data_ptr(), slab.numel(), raw)
+            for (x, dy, weight, row, s), dw in zip(entries, dws):
+                if weight.grad is None:
+                    weight.grad = dw
+                else:
+                    weight.grad.add_(dw)
+
+
 def _launch_wgrad(x, dy, weight, stride, pad, dil):
-    """dW [Cout, Cin, KH, KW] (channels-last memory) of a convolution; on the side stream when WGRAD_SIDE_STREAM is set."""
+    """dW [Cout, Cin, KH, KW] (channels-last memory) of a convolution; on the side stream when WGRAD_SIDE_STREAM is set.
+    (None, None) when the layer joined the grouped launch at the end of the backward pass (WGRAD_GROUPED)."""
     N, Cin, H, W = x.shape
     Cout, _, KH, KW = weight.shape
     OH, OW = dy.shape[2], dy.shape[3]
+    if WGRAD_GROUPED and not WGRAD_SIDE_STREAM and _defer_wgrad(x, dy, weight, stride, pad, dil):
+        return None, None
     lib = _lib.load()
     out_bf16 = weight.dtype == torch.bfloat16
     side = None

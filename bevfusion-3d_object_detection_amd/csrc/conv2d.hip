@@ -21,6 +21,10 @@
 // issued before the current step's MFMAs (one barrier per step).  LDS images are written linearly by the DMA; the bank
 // swizzle lives in the SOURCE chunk a lane fetches and in the read address (same involution on both sides).
 #include "common.h"
+#include <stddef.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
 
 namespace bfhip {
 namespace {
@@ -781,22 +785,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t *__rest
 // stage, each panel laid out exactly like the tiles above, (2 PG) x (2 PX) waves of 64 x 64 -- and keeps TWO stages in
 // flight behind the one being consumed (wait = vmcnt(pieces of one stage), one barrier per step): <1, 2> and <2, 1> move
 // 3/4 of the operand bytes per flop of the 128 x 128 tile with 96 KB continuously in flight per CU.
+// `lb`: this workgroup's index among the tiles_co * tiles_k * splits workgroups of the layer (split-major), `smem`: the dynamic LDS
 template <int PG, int PX, int STAGES>
-__global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const bf16_t *__restrict__ x,
-                                                                           const bf16_t *__restrict__ dy,
-                                                                           float *__restrict__ slab, WgradGeom wg) {
+__device__ __forceinline__ void wgrad_wide_body(const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy,
+                                                float *__restrict__ slab, const WgradGeom &wg, const long long lb,
+                                                unsigned char *smem) {
   constexpr int W = 4 * PG * PX;            // waves
   constexpr int GPW = 16 / W;               // 4-row groups of a 64-pixel stage staged by one wave
   static_assert(GPW >= 1 && GPW * W == 16, "waves must divide the 16 row groups of a stage");
   constexpr int BP = 64, PANEL = BP * 256;  // one panel: 64 pixels x 128 columns bf16
   constexpr int SB = (PG + PX) * PANEL;     // bytes of one stage
   constexpr int PER_STAGE = GPW * (PG + PX);  // DMA instructions per wave and stage
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned *taps = (unsigned *)(smem + STAGES * SB);
   const ConvGeom &g = wg.c;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index in an SGPR
   const int tiles = wg.tiles_co * wg.tiles_k;
-  const long long lb = xcd_chunked_block(blockIdx.x, (long long)tiles * wg.splits);
   const int split = (int)(lb / tiles), tile = (int)(lb - (long long)split * tiles);
   const int tco = tile / wg.tiles_k, tk = tile - tco * wg.tiles_k;
   const int co0 = tco * (128 * PG), q0 = tk * (16 * PX);  // first dy channel, first K piece of this tile
@@ -926,6 +929,67 @@ __global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const
   tr_store_slab(slab + (size_t)split * wg.Cout * Ktot, wg.Cout, Ktot, co0, q0, lane, wm, wn, acc);
 }
 
+template <int PG, int PX, int STAGES>
+__global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const bf16_t *__restrict__ x,
+                                                                           const bf16_t *__restrict__ dy,
+                                                                           float *__restrict__ slab, WgradGeom wg) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const long long lb = xcd_chunked_block(blockIdx.x, (long long)wg.tiles_co * wg.tiles_k * wg.splits);
+  wgrad_wide_body<PG, PX, STAGES>(x, dy, slab, wg, lb, smem);
+}
+
+// ---- Grouped weight gradients: the layers of a whole backward pass in ONE launch per tile shape.  dW of a layer is a leaf of the
+// backward graph, so the host (conv2d.py) only collects (x, dy, dW) during the backward and launches the group when the pass ends.
+// Launched one by one, each layer is cut into exactly one residency round (256 workgroups): 6-9 steps of 64 pixels per workgroup
+// on the ~50 small layers of the ResNet trunk, where the ring's prologue, the 128 KB slab store of every workgroup and the tail of
+// the launch cost more than the steps (28-45 us each at 170-310 TFLOP/s), and splits x dW fp32 slab bytes whatever the layer
+// (2.2 GB written per step).  In a group every workgroup runs ~`target_steps` steps of its layer (default 96): slab bytes fall
+// with the split count, and there is one tail per step instead of one per layer.
+// XCD placement: hardware workgroup b runs on XCD b % 8.  The host cuts the group's workgroup list (layers in descending order
+// of steps per workgroup, each layer split-major) into 8 consecutive chunks of equal total STEPS; XCD c works through chunk c in
+// order, so the tiles of one split (which share their x / dy rows) meet in one L2 and the 8 XCDs finish together.
+struct WgradItem {
+  unsigned long long x, dy, dw;          // bf16 [N,H,W,ldx], bf16 [N,OH,OW,ldg], dW (fp32 or bf16) [Cout][KH][KW][Cin]
+  unsigned long long slab_off;           // byte offset of this layer's splits x [Cout][Ktot] fp32 slabs in the group's workspace
+  long long M, rows_per_split, total;    // pixels, pixels per split (multiple of 64), Cout * Ktot
+  int N, H, W, C, ldx, OH, OW, KH, KW, stride, pad, dil, nq;
+  int Cout, ldg, splits, tiles_co, tiles_k;
+  int dw_bf16, shape;                    // shape: 1 = 128 co x 256 k, 2 = 256 co x 128 k
+  int first_block, n_blocks;             // in the launch of its shape (layer-local index = logical index - first_block)
+  int first_rblock, n_rblocks;           // in the reduce launch (one block = 1024 elements of dW)
+};
+struct WgradGroupHeader {                // first 256 bytes of the table image; the items follow
+  int n_items, n_shape[3], first_item[3], blocks[3], grid[3], max_nq[3], rblocks, target_steps;
+  int chunk_start[3][9];                 // logical block range of XCD c in the launch of shape s: [chunk_start[s][c], chunk_start[s][c + 1])
+  unsigned long long slab_bytes;
+};
+static_assert(sizeof(WgradGroupHeader) <= 256, "group header must fit its 256-byte slot");
+
+template <int PG, int PX, int STAGES>
+__global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_group_kernel(const WgradItem *__restrict__ items, int n_items,
+                                                                            const int *__restrict__ chunk_start,
+                                                                            unsigned char *__restrict__ slab_base) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int lbg = chunk_start[xcd] + slot;
+  if (lbg >= chunk_start[xcd + 1]) return;   // whole workgroup (uniform)
+  int lo = 0, hi = n_items - 1;              // last item with first_block <= lbg
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= lbg) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgradItem &it = items[lo];
+  WgradGeom wg;
+  ConvGeom &g = wg.c;
+  g.N = it.N; g.H = it.H; g.W = it.W; g.C = it.C; g.ldx = it.ldx; g.OH = it.OH; g.OW = it.OW;
+  g.KH = it.KH; g.KW = it.KW; g.stride = it.stride; g.pad = it.pad; g.dil = it.dil; g.nq = it.nq; g.M = it.M;
+  wg.Cout = it.Cout; wg.ldg = it.ldg; wg.splits = it.splits; wg.rows_per_split = it.rows_per_split;
+  wg.tiles_co = it.tiles_co; wg.tiles_k = it.tiles_k;
+  wgrad_wide_body<PG, PX, STAGES>((const bf16_t *)it.x, (const bf16_t *)it.dy, (float *)(slab_base + it.slab_off), wg,
+                                  (long long)(lbg - it.first_block), smem);
+}
+
 // ------------------------------------------------------------------------------------------------ sparse weight gradient
 // dW[co][k][ci] = sum over output rows of dout[row][co] * in[pairs[k][row]][ci]  (SubMConv3d / SparseConv3d, spconv's
 // (out, kD, kH, kW, in) weight layout): the dense kernel above with the rulebook as the gather -- column piece q of a tile is
@@ -1015,9 +1079,9 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_tr_kernel(const bf16_t *_
 
 // dW = sum over splits (fixed order), written as fp32 or bf16.  The loads of 8 slabs are issued before their adds: one
 // dependent round trip per 8 slabs instead of one per slab (18 slabs of the 128 -> 128 sparse layers: 31 -> ~8 us).
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ slab, int splits, long long total,
-                                                                void *__restrict__ dw, int out_bf16) {
-  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab, int splits, long long total,
+                                                  void *__restrict__ dw, int out_bf16, long long block) {
+  long long i = (block * 256 + threadIdx.x) * 4;
   if (i >= total) return;
   if (i + 4 <= total) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1047,6 +1111,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
       else ((float *)dw)[e] = a;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ slab, int splits, long long total,
+                                                                void *__restrict__ dw, int out_bf16) {
+  wgrad_reduce_body(slab, splits, total, dw, out_bf16, blockIdx.x);
+}
+
+// every layer of a group in one launch: block -> layer by its first reduce block
+__global__ __launch_bounds__(256) void conv_wgrad_group_reduce_kernel(const WgradItem *__restrict__ items, int n_items,
+                                                                      const unsigned char *__restrict__ slab_base) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_rblock <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgradItem &it = items[lo];
+  wgrad_reduce_body((const float *)(slab_base + it.slab_off), it.splits, it.total, (void *)it.dw, it.dw_bf16, b - it.first_rblock);
 }
 
 // Wt'[ci][kh][kw][co] = W[co][kh][kw][ci]  (the dgrad's B^T operand)
@@ -1587,4 +1670,180 @@ BFHIP_EXPORT int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int 
                      total, dw, dw_bf16);
   prof_end(&ps);
   return check_launch("conv2d_wgrad");
+}
+
+// ---------------------------------------------------------------------------------- grouped weight gradients (host side)
+// One record per layer, filled by the caller in host memory (include/bevfusion_hip.h: bfhip_wgrad_layer).
+struct WgradLayerDesc {
+  const void *x, *dy;
+  void *dw;
+  int ldx, ldg, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, dw_bf16, reserved;
+};
+static_assert(sizeof(WgradLayerDesc) == 80, "bfhip_wgrad_layer layout");
+
+BFHIP_EXPORT size_t bfhip_conv2d_wgrad_group_table_bytes(int n_layers) {
+  return n_layers > 0 ? 256 + (size_t)n_layers * sizeof(WgradItem) : 0;
+}
+
+// 1 when the layer can join a group: a geometry the wide weight-gradient kernels take (everything else keeps bfhip_conv2d_wgrad)
+BFHIP_EXPORT int bfhip_conv2d_wgrad_groupable(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
+  if (!bfhip_conv2d_supported(N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return 0;
+  const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  return wgrad_shape((long long)N * OH * OW, Cout, KH * KW * Cin, (long long)OH * OW) != 0;
+}
+
+// Plans the group and writes the image of its device table (header + one item per layer) into table_host; the caller copies
+// the image to the device (stream-ordered, before the launch) and provides *slab_bytes of workspace.  target_steps: 64-pixel
+// steps per workgroup to aim for (<= 0: BFHIP_WGRAD_GROUP_STEPS or 96).
+BFHIP_EXPORT int bfhip_conv2d_wgrad_group_plan(const void *layers_, int n, int target_steps, void *table_host, size_t table_bytes,
+                                               size_t *slab_bytes) {
+  const WgradLayerDesc *L = (const WgradLayerDesc *)layers_;
+  BFHIP_REQUIRE(L && n > 0 && table_host && slab_bytes, "conv2d_wgrad_group_plan: bad arguments");
+  BFHIP_REQUIRE(table_bytes >= bfhip_conv2d_wgrad_group_table_bytes(n), "conv2d_wgrad_group_plan: table too small");
+  if (target_steps <= 0) {
+    static const int env = [] { const char *e = getenv("BFHIP_WGRAD_GROUP_STEPS"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
+    target_steps = env;
+  }
+  WgradGroupHeader hd;
+  memset(&hd, 0, sizeof hd);
+  hd.n_items = n;
+  hd.target_steps = target_steps;
+  std::vector<WgradItem> items((size_t)n);
+  std::vector<long long> per((size_t)n);
+  long long shape_steps[3] = {0, 0, 0};
+  int shape_target[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const WgradLayerDesc &d = L[i];
+    BFHIP_REQUIRE(d.x && d.dy && d.dw, "conv2d_wgrad_group_plan: null pointer in a layer");
+    BFHIP_REQUIRE(bfhip_conv2d_wgrad_groupable(d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil),
+                  "conv2d_wgrad_group_plan: a layer is not groupable (ask bfhip_conv2d_wgrad_groupable first)");
+    BFHIP_REQUIRE(((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.dy % 16) == 0 && ((uintptr_t)d.dw % 16) == 0 && d.ldx % 8 == 0 &&
+                  d.ldg % 8 == 0 && d.ldx >= d.Cin && d.ldg >= d.Cout,
+                  "conv2d_wgrad_group_plan: operands must be 16-byte aligned with pitches that are multiples of 8 elements");
+    WgradItem &it = items[i];
+    memset(&it, 0, sizeof it);
+    it.x = (unsigned long long)(uintptr_t)d.x; it.dy = (unsigned long long)(uintptr_t)d.dy; it.dw = (unsigned long long)(uintptr_t)d.dw;
+    it.N = d.N; it.H = d.H; it.W = d.W; it.C = d.Cin; it.ldx = d.ldx;
+    it.OH = (d.H + 2 * d.pad - d.dil * (d.KH - 1) - 1) / d.stride + 1;
+    it.OW = (d.W + 2 * d.pad - d.dil * (d.KW - 1) - 1) / d.stride + 1;
+    it.KH = d.KH; it.KW = d.KW; it.stride = d.stride; it.pad = d.pad; it.dil = d.dil;
+    const int Ktot = d.KH * d.KW * d.Cin;
+    it.nq = Ktot / 8;
+    it.M = (long long)d.N * it.OH * it.OW;
+    it.Cout = d.Cout; it.ldg = d.ldg; it.dw_bf16 = d.dw_bf16;
+    BFHIP_REQUIRE((long long)d.N * d.H * d.W * d.ldx < (1LL << 31) && it.M * d.ldg < (1LL << 31),
+                  "conv2d_wgrad_group_plan: tensors of 2^31 elements or more are not supported");
+    it.shape = wgrad_shape(it.M, d.Cout, Ktot, (long long)it.OH * it.OW);
+    it.tiles_co = ceil_div(d.Cout, it.shape == 2 ? 256 : 128);
+    it.tiles_k = ceil_div(Ktot, it.shape == 1 ? 256 : 128);
+    it.total = (long long)d.Cout * Ktot;
+    it.n_rblocks = (int)ceil_div(it.total, 1024);
+    shape_steps[it.shape] += (long long)it.tiles_co * it.tiles_k * ((it.M + 63) / 64);
+  }
+  // steps per workgroup: the target, lowered for a launch that would otherwise have fewer than ~4 residency rounds of workgroups
+  // (the 9 layers with K <= 128 of the ResNet trunk at 96 steps: 285 workgroups on 256 CUs = two rounds, the second one empty)
+  for (int sh = 1; sh <= 2; ++sh) {
+    long long t = shape_steps[sh] / 1024;
+    shape_target[sh] = (int)std::min<long long>(target_steps, std::max<long long>(8, t));
+  }
+  for (int i = 0; i < n; ++i) {
+    WgradItem &it = items[i];
+    const int tgt = shape_target[it.shape];
+    const long long steps = (it.M + 63) / 64;
+    long long want = (steps + tgt / 2) / tgt;
+    if (want > steps / 6) want = steps / 6;  // the ring is three deep: at least 6 steps per workgroup
+    if (want < 1) want = 1;
+    per[i] = (steps + want - 1) / want;
+    it.splits = (int)((steps + per[i] - 1) / per[i]);
+    it.rows_per_split = per[i] * 64;
+    it.n_blocks = it.tiles_co * it.tiles_k * it.splits;
+  }
+  // table order: shape 1 then shape 2, inside a shape by descending steps per workgroup (ties: caller's order)
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (items[a].shape != items[b].shape) return items[a].shape < items[b].shape;
+    return per[a] > per[b];
+  });
+  WgradItem *out = (WgradItem *)((unsigned char *)table_host + 256);
+  size_t slab = 0;
+  long long rb = 0;
+  for (int sh = 1; sh <= 2; ++sh) hd.first_item[sh] = -1;
+  for (int k = 0; k < n; ++k) {
+    WgradItem it = items[order[k]];
+    const int sh = it.shape;
+    if (hd.first_item[sh] < 0) hd.first_item[sh] = k;
+    ++hd.n_shape[sh];
+    it.first_block = hd.blocks[sh];
+    BFHIP_REQUIRE((long long)hd.blocks[sh] + it.n_blocks < (1LL << 30), "conv2d_wgrad_group_plan: too many workgroups");
+    hd.blocks[sh] += it.n_blocks;
+    if (it.nq > hd.max_nq[sh]) hd.max_nq[sh] = it.nq;
+    it.slab_off = slab;
+    slab += align_up((size_t)it.splits * it.total * sizeof(float), 256);
+    it.first_rblock = (int)rb;
+    rb += it.n_rblocks;
+    BFHIP_REQUIRE(rb < (1LL << 30), "conv2d_wgrad_group_plan: too many reduce blocks");
+    out[k] = it;
+  }
+  hd.rblocks = (int)rb;
+  hd.slab_bytes = slab;
+  // XCD chunks of equal total steps (a workgroup's cost = its step count; all workgroups of one launch have the same tile shape)
+  for (int sh = 1; sh <= 2; ++sh) {
+    if (!hd.n_shape[sh]) continue;
+    const WgradItem *its = out + hd.first_item[sh];
+    long long total_steps = 0;
+    for (int k = 0; k < hd.n_shape[sh]; ++k) total_steps += (long long)its[k].n_blocks * (its[k].rows_per_split / 64);
+    int c = 1, longest = 0;
+    long long acc = 0;
+    hd.chunk_start[sh][0] = 0;
+    for (int k = 0; k < hd.n_shape[sh]; ++k) {
+      const long long w = its[k].rows_per_split / 64;
+      for (int b = 0; b < its[k].n_blocks; ++b) {
+        // block (first_block + b) opens chunk c when the steps before it reach c/8 of the total
+        while (c < 8 && acc * 8 >= total_steps * c) hd.chunk_start[sh][c++] = its[k].first_block + b;
+        acc += w;
+      }
+    }
+    while (c <= 8) hd.chunk_start[sh][c++] = hd.blocks[sh];
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, hd.chunk_start[sh][x + 1] - hd.chunk_start[sh][x]);
+    hd.grid[sh] = 8 * longest;
+  }
+  memcpy(table_host, &hd, sizeof hd);
+  *slab_bytes = slab;
+  return 0;
+}
+
+// table_host: the image bfhip_conv2d_wgrad_group_plan wrote (its header is read here), table_dev: its device copy
+BFHIP_EXPORT int bfhip_conv2d_wgrad_group_launch(const void *table_host, const void *table_dev, void *slab, size_t slab_bytes,
+                                                 void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  BFHIP_REQUIRE(table_host && table_dev && slab, "conv2d_wgrad_group_launch: null pointer");
+  WgradGroupHeader hd;
+  memcpy(&hd, table_host, sizeof hd);
+  BFHIP_REQUIRE(hd.n_items > 0 && hd.n_items == hd.n_shape[1] + hd.n_shape[2], "conv2d_wgrad_group_launch: not a planned table");
+  BFHIP_REQUIRE(slab_bytes >= hd.slab_bytes && ((uintptr_t)slab % 256) == 0, "conv2d_wgrad_group_launch: workspace too small or misaligned");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_group_kernel<1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_group_kernel<2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const WgradItem *items = (const WgradItem *)((const unsigned char *)table_dev + 256);
+  const int *chunks = (const int *)((const unsigned char *)table_dev + offsetof(WgradGroupHeader, chunk_start));
+  ProfScope ps;
+  prof_begin(BFHIP_OP_CONV2D_WGRAD, s, &ps);
+  for (int sh = 1; sh <= 2; ++sh) {
+    if (!hd.n_shape[sh]) continue;
+    const size_t lds = (size_t)3 * 3 * 64 * 256 + (size_t)hd.max_nq[sh] * 4;
+    if (sh == 1)
+      hipLaunchKernelGGL((conv_wgrad_group_kernel<1, 2, 3>), dim3((unsigned)hd.grid[sh]), dim3(512), lds, s, items + hd.first_item[sh],
+                         hd.n_shape[sh], chunks + sh * 9, (unsigned char *)slab);
+    else
+      hipLaunchKernelGGL((conv_wgrad_group_kernel<2, 1, 3>), dim3((unsigned)hd.grid[sh]), dim3(512), lds, s, items + hd.first_item[sh],
+                         hd.n_shape[sh], chunks + sh * 9, (unsigned char *)slab);
+  }
+  hipLaunchKernelGGL(conv_wgrad_group_reduce_kernel, dim3((unsigned)hd.rblocks), dim3(256), 0, s, items, hd.n_items,
+                     (const unsigned char *)slab);
+  prof_end(&ps);
+  return check_launch("conv2d_wgrad_group");
 }

@@ -522,6 +522,29 @@ size_t bfhip_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Co
 int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw, int N, int H, int W, int Cin, int Cout,
                        int KH, int KW, int stride, int pad, int dil, int dw_bf16, void *workspace, size_t workspace_bytes,
                        void *stream);
+/* Grouped weight gradients: dW of MANY layers in one launch per tile shape plus one slab-sum launch.  dW of a layer is a leaf of
+ * the backward graph (torch/nn/modules/conv.py's weight gradient, reached through BF/bevfusion.py:143-171 and every ConvModule of
+ * the dense path), so a caller may collect (x, dy, dW) during the backward and launch the group at its end: every workgroup then
+ * runs ~target_steps 64-pixel steps of its layer instead of the 6-9 a one-residency-round launch of a small layer leaves it,
+ * and the fp32 split slabs shrink with the split count.  Same kernels, same fixed-order slab sum as bfhip_conv2d_wgrad; only the
+ * number of splits (= the fp32 summation order) differs.
+ *   bfhip_wgrad_layer                    one record per layer, host memory, filled by the caller
+ *   bfhip_conv2d_wgrad_groupable()       1 if the layer's geometry can join a group (else: bfhip_conv2d_wgrad)
+ *   bfhip_conv2d_wgrad_group_table_bytes size of the table image for n layers
+ *   bfhip_conv2d_wgrad_group_plan()      host only: plans splits / XCD chunks, writes the table image into table_host (host memory,
+ *                                        e.g. pinned) and the slab workspace size into *slab_bytes; target_steps <= 0: default 96
+ *   bfhip_conv2d_wgrad_group_launch()    table_dev = device copy of the image (copied by the caller, stream-ordered before this
+ *                                        call); slab: 256-byte aligned device workspace of >= *slab_bytes */
+typedef struct bfhip_wgrad_layer {
+  const void *x, *dy; /* bf16 [N,H,W,ldx] and bf16 [N,OH,OW,ldg], 16-byte aligned */
+  void *dw;           /* [Cout][KH][KW][Cin], fp32 or bf16 (dw_bf16) */
+  int32_t ldx, ldg, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, dw_bf16, reserved;
+} bfhip_wgrad_layer;
+size_t bfhip_conv2d_wgrad_group_table_bytes(int n_layers);
+int bfhip_conv2d_wgrad_groupable(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil);
+int bfhip_conv2d_wgrad_group_plan(const void *layers, int n_layers, int target_steps, void *table_host, size_t table_bytes,
+                                  size_t *slab_bytes);
+int bfhip_conv2d_wgrad_group_launch(const void *table_host, const void *table_dev, void *slab, size_t slab_bytes, void *stream);
 /* BatchNorm2d forward whose statistics pass already happened in the producing convolution's epilogue: `partial`
  * f32[nblk][2][C] (column sums, sums of squares per row block).  Otherwise as bfhip_bn2d_fwd. */
 int bfhip_bn2d_fwd_partials(const void *x, const void *residual, const float *gamma, const float *beta, long long M, int C,

@@ -240,6 +240,7 @@ def test_weight_gradients_on_the_side_stream_are_identical(dev, monkeypatch):
         m.weight.data = m.weight.data.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     x = torch.randn(3, 32, 64, 88, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     grads = {}
+    monkeypatch.setattr(c2, "WGRAD_GROUPED", False)  # the in-line launches are the ones compared bit for bit here
     for side in (False, True):
         monkeypatch.setattr(c2, "WGRAD_SIDE_STREAM", side)
         got = []
@@ -262,6 +263,102 @@ def test_weight_gradients_on_the_side_stream_are_identical(dev, monkeypatch):
     assert all(torch.isfinite(g.float()).all() and g.float().abs().sum() > 0 for g in grads[True])
     for a, b in zip(grads[False], grads[True]):
         assert torch.equal(a, b)
+
+
+def _wgrad_stack(dev, dtype):
+    """A small network that covers both tile shapes of the grouped launch (K > 128: 128 co x 256 k; K <= 128 with Cout > 128:
+    256 co x 128 k), a stride-2 3x3 layer, a layer that is NOT groupable (stride 4 onto a 6 x 11 map: 198 output pixels, fewer
+    than the six 64-pixel steps the wide kernels want -> its own launch inside the pass), a layer the library serves (its input
+    has fewer than conv2d.MIN_PIXELS pixels) and a weight that is used twice (two records for one parameter)."""
+    from bevfusion_amd.conv2d import Conv2d
+    torch.manual_seed(0)
+    convs = torch.nn.ModuleList([Conv2d(32, 64, 3, padding=1, bias=False), Conv2d(64, 64, 3, stride=2, padding=1, bias=False),
+                                 Conv2d(64, 256, 1, bias=False), Conv2d(256, 64, 1, bias=False), Conv2d(64, 64, 3, padding=1, bias=True),
+                                 Conv2d(64, 32, 3, stride=4, padding=1, bias=False), Conv2d(32, 32, 3, padding=1, bias=False)]).to(dev).train()
+    for m in convs:
+        m.weight.data = m.weight.data.to(dtype).contiguous(memory_format=torch.channels_last)
+
+    def run(x):
+        h = convs[1](convs[0](x))
+        h = convs[3](convs[2](h))
+        h = convs[4](convs[4](h))       # shared weight
+        h = convs[6](convs[5](h))       # [3, 32, 6, 11]
+        return h
+    return convs, run
+
+
+@pytest.mark.parametrize("wdtype", [torch.bfloat16, torch.float32])
+def test_grouped_weight_gradients_match_the_in_line_launches(dev, monkeypatch, wdtype):
+    """conv2d.WGRAD_GROUPED (csrc/conv2d.hip: conv_wgrad_group_kernel): dW of all layers of a backward pass in one launch per tile
+    shape at the end of the pass equals the per-layer launches up to the fp32 summation order (the pixel range is cut into a
+    different number of splits: <= 1e-5 rel on fp32 dW, one bf16 rounding on bf16 dW); the gradients are in place when
+    backward() returns, a second pass without clearing .grad accumulates, and the result is deterministic."""
+    from bevfusion_amd import conv2d as c2
+    convs, run = _wgrad_stack(dev, wdtype)
+    x = torch.randn(3, 32, 48, 88, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    calls = []
+    orig = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+    res = {}
+    for grouped in (False, True, True):
+        monkeypatch.setattr(c2, "WGRAD_GROUPED", grouped)
+        del calls[:]
+        for p in convs.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            run(x).float().square().mean().backward()
+        first = [p.grad.clone() for p in convs.parameters()]     # readable as soon as backward() has returned
+        n_inline, n_group = calls.count("bfhip_conv2d_wgrad"), calls.count("bfhip_conv2d_wgrad_group_launch")
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            run(x).float().square().mean().backward()            # accumulates into the existing .grad
+        second = [p.grad.clone() for p in convs.parameters()]
+        torch.cuda.synchronize()
+        res.setdefault(grouped, []).append((first, second, n_inline, n_group))
+    (f0, s0, inline0, group0), = res[False]
+    (f1, s1, inline1, group1), (f2, s2, _, _) = res[True]
+    assert (inline0, group0) == (7, 0) and (inline1, group1) == (1, 1)   # 7 HIP conv calls; only the 6 x 11 layer keeps its own launch
+    assert not c2._PENDING
+    tol = 1e-5 if wdtype == torch.float32 else 2.0 ** -7
+    for a, b, a2, b2 in zip(f0, f1, s0, s1):
+        assert torch.isfinite(b.float()).all() and b.float().abs().sum() > 0
+        assert _l2(a.float(), b.float()) < tol, _l2(a.float(), b.float())
+        assert _l2(a2.float(), b2.float()) < 2 * tol
+        assert _l2(b2.float(), 2 * b.float()) < 2.0 ** -7                # second pass added the same gradient
+    for b, c in zip(f1 + s1, f2 + s2):
+        assert torch.equal(b, c)                                         # fixed-order slab sums: bit-identical run to run
+
+
+def test_grouped_weight_gradient_full_size_linearity(dev):
+    """Size-independent property at the ConvFuser's real size (4 x 336 x 180 x 180 -> 256, 3x3): dW is linear in dy, so
+    dW(dy1 + dy2) = dW(dy1) + dW(dy2) up to bf16 rounding of the operands -- checked on fp32 weights with dy values that are
+    exact in bf16 (small integers), where every product and every partial sum below 2^24 is exact: the three gradients must
+    then agree BIT FOR BIT whatever the split count."""
+    from bevfusion_amd import conv2d as c2
+    from bevfusion_amd.conv2d import Conv2d
+    torch.manual_seed(1)
+    conv = Conv2d(336, 256, 3, padding=1, bias=False).to(dev).train()
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = torch.randint(-2, 3, (4, 336, 180, 180), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dys = [torch.randint(-2, 3, (4, 256, 180, 180), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+           for _ in range(2)]
+    out = []
+    for dy in (dys[0], dys[1], dys[0] + dys[1]):
+        conv.weight.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            conv(x).backward(dy)
+        out.append(conv.weight.grad.clone())
+    assert out[2].abs().max() < 2 ** 24 and out[2].abs().sum() > 0
+    assert torch.equal(out[0] + out[1], out[2])
+    # and against the per-layer launch: integers again, so the different split count cannot show
+    c2.WGRAD_GROUPED = False
+    try:
+        conv.weight.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            conv(x).backward(dys[0] + dys[1])
+    finally:
+        c2.WGRAD_GROUPED = True
+    assert torch.equal(conv.weight.grad, out[2])
 
 
 def test_epilogue_statistics_do_not_survive_an_in_place_edit(dev):

@@ -30,7 +30,8 @@ FAMILIES = {
     "conv2d_dgrad": [r"conv_igemm_kernel<[^>]*, [12]>", r"conv_weight_transpose_kernel"],
     "conv2d_pw_fwd": [r"conv_pw_kernel<[^>]*, 0>"],
     "conv2d_pw_dgrad": [r"conv_pw_kernel<[^>]*, 1>"],
-    "conv2d_wgrad": [r"conv_wgrad_kernel", r"conv_wgrad_wide_kernel", r"conv_wgrad_reduce_kernel"],
+    "conv2d_wgrad": [r"conv_wgrad_kernel", r"conv_wgrad_wide_kernel", r"conv_wgrad_reduce_kernel", r"conv_wgrad_group_kernel",
+                     r"conv_wgrad_group_reduce_kernel"],
     "bn2d_fwd": [r"bn2d_stats", r"bn2d_finalize_kernel<[^>]*FwdFin", r"bn2d_apply"],
     "bn2d_bwd": [r"bn2d_bwd", r"bn2d_finalize_kernel<[^>]*BwdFin"],
 }
@@ -120,8 +121,10 @@ def main(line_path, trace_path, plain_path=None):
         if op == "conv2d_wgrad" and "spconv_wgrad_main" in bench:  # remove the sparse layers' share of the shared slab-sum kernel
             red = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[lo:hi] if "conv_wgrad_reduce_kernel" in r["Kernel_Name"]]
             per = len(red) / n_steps
-            if per > 77:
-                cut = sum(red) / 1e6 / n_steps * (per - 77) / per
+            # every dense per-layer launch has exactly one slab sum behind its main kernel (the grouped launch has its own reduce kernel)
+            dense = sum(1 for r in rows[lo:hi] if re.search(r"conv_wgrad_kernel|conv_wgrad_wide_kernel", r["Kernel_Name"])) / n_steps
+            if per > dense:
+                cut = sum(red) / 1e6 / n_steps * (per - dense) / per
                 t -= cut
                 sp -= cut
         ratio = b / sp if sp else float("nan")

@@ -17,6 +17,9 @@ import torch.nn.functional as F  # noqa: E402
 
 import bevfusion_amd  # noqa: E402,F401
 from bevfusion_amd.conv2d import conv2d  # noqa: E402
+from bevfusion_amd import conv2d as _c2  # noqa: E402
+
+_c2.WGRAD_GROUPED = False  # torch.autograd.grad w.r.t. the weight below: each layer launches its own weight gradient
 
 #          name                 N   H    W    Cin  Cout k s p
 LAYERS = [("ConvFuser",          4, 180, 180, 336, 256, 3, 1, 1),

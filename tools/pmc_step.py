@@ -14,7 +14,7 @@ import sys
 FAMILIES = [
     ("spconv_wgrad", lambda n: "spconv_wgrad" in n),
     ("wgrad_reduce + offset counts", lambda n: ("wgrad_reduce" in n and "conv_wgrad_reduce" not in n) or "wgrad_offset_counts" in n),
-    ("conv_wgrad_reduce (slab sum of the sparse bf16 and the dense weight gradients)", lambda n: "conv_wgrad_reduce" in n),
+    ("conv_wgrad_reduce (slab sum of the sparse bf16 and the dense weight gradients)", lambda n: "conv_wgrad_reduce" in n or "conv_wgrad_group_reduce" in n),
     ("spconv_gemm (fwd + dgrad)", lambda n: "spconv_gemm" in n),
     ("bn2d backward (reduce, finalize, apply)", lambda n: "bn2d_bwd" in n or ("bn2d_finalize" in n and "BwdFin" in n)),
     ("bn2d forward (stats, finalize, apply)", lambda n: "bn2d_" in n),
@@ -24,7 +24,7 @@ FAMILIES = [
     ("conv2d pointwise forward (conv_pw)", lambda n: "conv_pw_kernel" in n),
     ("conv2d dgrad (conv_igemm, transposed gather)", lambda n: re.search(r"conv_igemm_kernel<[^>]*, [12]>", n) is not None),
     ("conv2d forward (conv_igemm)", lambda n: "conv_igemm_kernel" in n),
-    ("conv2d wgrad (main kernel)", lambda n: "conv_wgrad_kernel" in n or "conv_wgrad_wide_kernel" in n),
+    ("conv2d wgrad (main kernel)", lambda n: "conv_wgrad_kernel" in n or "conv_wgrad_wide_kernel" in n or "conv_wgrad_group_kernel" in n),
     ("conv weight transpose", lambda n: "conv_weight_transpose" in n),
     ("bn1d", lambda n: "bn1d_" in n),
     ("attn (all)", lambda n: "attn_" in n),
