@@ -255,6 +255,11 @@ class _ModelWorkload:
         # opt-in: over 6 + 6 alternating runs on one box the third queue changes the mean step time by +0.1 ms (31.35 vs
         # 31.21 ms) and widens its spread (30.5 ... 32.5 vs 31.0 ... 31.4 ms): the weight gradients fill the chip by themselves
         _c2.WGRAD_SIDE_STREAM = os.environ.get("BENCH_WGRAD_SIDE_STREAM", "0") == "1"
+        if ddp and GRAD_SYNC == "ddp":
+            # torch DDP reduces a bucket from the AccumulateGrad hooks of its parameters; the grouped weight gradients store .grad
+            # themselves at the end of the pass and never reach those hooks
+            _c2.WGRAD_GROUPED = False
+        self.wgrad_grouped = bool(_c2.WGRAD_GROUPED and not _c2.WGRAD_SIDE_STREAM and not self.use_graph)
         self._wgrad_join = _c2.wgrad_join if _c2.WGRAD_SIDE_STREAM else None
         self._params = [p for p in self.model.parameters() if p.requires_grad]
         # ground truth as a dataloader hands it over: per-frame host tensors (boxes [G, 9], labels [G]), G ~ U(15, 60)
@@ -912,6 +917,8 @@ def main():
             line["config"]["head_fp32_conv"] = ("three bf16 products per multiply, fp32 accumulation (2^-16 relative per product)"
                                                 if _c2i.FP32_SPLIT else "library fp32")
         if hasattr(wl, "n_params"):
+            line["config"]["dense_weight_gradients"] = ("one grouped launch per tile shape at the end of the backward pass"
+                                                        if getattr(wl, "wgrad_grouped", False) else "one launch pair per layer")
             line["config"]["trainable_params"] = wl.n_params
         if torch.is_tensor(first_loss) and torch.is_tensor(last_loss):
             # the optimizer really steps: total loss of the (fixed) batch at the first warm-up step and at the last timed step

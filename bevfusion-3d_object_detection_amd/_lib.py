@@ -60,6 +60,8 @@ SIGNATURES = {
     "bfhip_dynamic_scatter_bwd": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp, _c_sz, _c_vp]),
     "bfhip_voxel_mean": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "bfhip_voxel_compact_mean": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp] * 4),
+    "bfhip_depth_lift_bwd_workspace_bytes": (_c_sz, []),
+    "bfhip_depth_lift_bwd": (_c_int, [_c_vp, _c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_sz, _c_vp]),
     "bfhip_rasterise_depth_workspace_bytes": (_c_sz, [_c_int] * 3),
     "bfhip_rasterise_depth": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 4 + [_c_int] * 3 + [_c_vp, _c_vp] + [_c_int] * 3 +
                               [_c_vp, _c_vp, _c_sz, _c_vp]),

@@ -61,7 +61,8 @@ def wgrad_join():
 # `weight.grad` itself -- what AccumulateGrad would have done.  Consequences: x and dy of every layer live until the end of the
 # pass (a few GB at batch 4 beside 288 GB of HBM); tensor hooks on a conv WEIGHT do not fire for this gradient; and
 # `torch.autograd.grad(..., weight)` finds no gradient for the weight (it raises "appears to not have been used") -- switch the
-# grouping off for such calls.  Not used while a HIP graph is being captured (the table upload is host memory of this step) or
+# grouping off for such calls, and under torch's DistributedDataParallel, whose bucket all-reduce is driven by the AccumulateGrad
+# hooks this path never reaches (grad_sync.FlatGradAllReduce, which runs after the pass, is fine).  Not used while a HIP graph is being captured (the table upload is host memory of this step) or
 # with the side-stream option above.
 WGRAD_GROUPED = os.environ.get("BFHIP_WGRAD_GROUPED", "1") == "1"
 _PENDING = []      # (x, dy, weight, row of the layer table, producing stream) of the running backward pass

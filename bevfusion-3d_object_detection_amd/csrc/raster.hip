@@ -110,6 +110,53 @@ __global__ __launch_bounds__(256) void hist_normalise_kernel(const float *__rest
   for (int b = lane; b < D; b += 64) distr[cell * D + b] = c[b] / den;
 }
 
+// ---- gradient of the first dtransform layer, Conv2d(1, 8, 1) on the one-channel depth image (BF/depth_lss.py:592-594):
+// y[m][c] = b[c] + d[m] * w[c], so dw[c] = sum_m dy[m][c] * d[m] and db[c] = sum_m dy[m][c] over the BN * 256 * 704 pixels.
+// torch forms dy * d as a tensor and reduces two [4.3 M, 8] tensors along their long side (2 x 160 us at 0.43 TB/s: eight-wide
+// rows defeat its reduction's vectorisation); here one pass over dy (16 B per row) and d, fp32 accumulation, block partials
+// summed in a fixed order by the second kernel.
+constexpr int kLiftBlocks = 2048;
+
+__global__ __launch_bounds__(256) void depth_lift_bwd_kernel(const uint4 *__restrict__ dy, const unsigned short *__restrict__ d,
+                                                             long long M, float *__restrict__ partial) {
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    const uint4 v = dy[m];
+    const float dv = __uint_as_float((unsigned)d[m] << 16);
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+      acc[2 * k] += lo;
+      acc[2 * k + 1] += hi;
+      acc[8 + 2 * k] += lo * dv;
+      acc[8 + 2 * k + 1] += hi * dv;
+    }
+  }
+  __shared__ float red[4][16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float a = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) partial[(size_t)blockIdx.x * 16 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[0..8) = db, out[8..16) = dw: 16 threads per output, each a fixed slice of the block partials, then a fixed tree
+__global__ __launch_bounds__(256) void depth_lift_bwd_final_kernel(const float *__restrict__ partial, int nblk, float *__restrict__ out) {
+  const int o = threadIdx.x >> 4, part = threadIdx.x & 15;
+  double a = 0.0;
+  for (int b = part; b < nblk; b += 16) a += (double)partial[(size_t)b * 16 + o];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) a += __shfl_down(a, off, 16);
+  if (part == 0) out[o] = (float)a;
+}
+
 }  // namespace
 }  // namespace bfhip
 
@@ -152,6 +199,22 @@ BFHIP_EXPORT int bfhip_rasterise_depth(const float *points, int n, int f, const 
                      lo, cmax, half, step, depth, counts);
   prof_end(&ps);
   return check_launch("rasterise_depth");
+}
+
+BFHIP_EXPORT size_t bfhip_depth_lift_bwd_workspace_bytes(void) { return (size_t)kLiftBlocks * 16 * sizeof(float); }
+
+// dy bf16 [M][8] (dense), d bf16 [M] -> out f32[16] = {db[8], dw[8]} of y[m][c] = b[c] + d[m] * w[c]
+BFHIP_EXPORT int bfhip_depth_lift_bwd(const void *dy, const void *d, long long M, float *out, void *workspace, size_t workspace_bytes,
+                                      void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BFHIP_REQUIRE(dy && d && out && M > 0, "depth_lift_bwd: bad arguments");
+  BFHIP_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)d % 2) == 0, "depth_lift_bwd: misaligned tensor");
+  if (!workspace || workspace_bytes < bfhip_depth_lift_bwd_workspace_bytes()) { set_error("depth_lift_bwd: workspace too small"); return BFHIP_E_WORKSPACE; }
+  const int nblk = (int)(M < (long long)kLiftBlocks * 256 ? ceil_div(M, 256) : kLiftBlocks);
+  hipLaunchKernelGGL(depth_lift_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const uint4 *)dy, (const unsigned short *)d, M,
+                     (float *)workspace);
+  hipLaunchKernelGGL(depth_lift_bwd_final_kernel, dim3(1), dim3(256), 0, stream, (const float *)workspace, nblk, out);
+  return check_launch("depth_lift_bwd");
 }
 
 // counts (optional input, f32[BN,fH,fW,D]) -> distr; when depth != NULL the counts are first rebuilt from it.

@@ -485,6 +485,31 @@ class BaseDepthTransform(BaseViewTransform):
         return torch.sum(cross_ent * mask_flat.float()) / (mask_flat.sum() + 1e-8)
 
 
+class _DepthLift(torch.autograd.Function):
+    """y [BN, H, W, 8] = bias + d [BN, H, W, 1] * weight -- Conv2d(1, 8, 1) on the one-channel depth image (reference :592-594) in
+    bf16, written channels-last.  Backward: csrc/raster.hip depth_lift_bwd_kernel (dw = sum dy * d, db = sum dy in one pass)."""
+
+    @staticmethod
+    def forward(ctx, d, weight, bias):
+        y = torch.addcmul(bias.to(d.dtype), d, weight.reshape(1, 1, 1, -1).to(d.dtype))
+        ctx.save_for_backward(d)
+        ctx.dtypes = (weight.dtype, bias.dtype, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (d,) = ctx.saved_tensors
+        wdt, bdt, wshape = ctx.dtypes
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous() or dy.data_ptr() % 16:
+            dy = dy.to(torch.bfloat16).contiguous()
+        from . import _lib
+        out = torch.empty(16, dtype=torch.float32, device=dy.device)
+        ws = torch.empty(_lib.call_size("bfhip_depth_lift_bwd_workspace_bytes"), dtype=torch.uint8, device=dy.device)
+        _lib.call("bfhip_depth_lift_bwd", dy.data_ptr(), d.data_ptr(), d.numel(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                  _lib.stream_of(dy))
+        return None, out[8:].to(wdt).reshape(wshape), out[:8].to(bdt)
+
+
 @MODELS.register_module()
 class DepthLSSTransform(BaseDepthTransform):
     """(reference :555-733) dtransform on the sparse depth image + depthnet on cat(depth feats, image feats)."""
@@ -512,9 +537,14 @@ class DepthLSSTransform(BaseDepthTransform):
             return self.dtransform(d)
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else d.dtype
         BN, _, H, W = d.shape
-        w = conv0.weight.reshape(1, 1, 1, -1).to(dt)
-        b = (conv0.bias if conv0.bias is not None else conv0.weight.new_zeros(w.shape[-1])).to(dt)
-        y = torch.addcmul(b, d.reshape(BN, H, W, 1).to(dt), w).permute(0, 3, 1, 2)  # [BN, 8, H, W], channels-last strides
+        if (dt == torch.bfloat16 and conv0.out_channels == 8 and conv0.bias is not None and torch.is_grad_enabled()
+                and conv0.weight.requires_grad and not d.requires_grad):
+            # same forward; the two parameter gradients in one pass over dy instead of a product tensor and two long reductions
+            y = _DepthLift.apply(d.reshape(BN, H, W, 1).to(dt), conv0.weight, conv0.bias).permute(0, 3, 1, 2)
+        else:
+            w = conv0.weight.reshape(1, 1, 1, -1).to(dt)
+            b = (conv0.bias if conv0.bias is not None else conv0.weight.new_zeros(w.shape[-1])).to(dt)
+            y = torch.addcmul(b, d.reshape(BN, H, W, 1).to(dt), w).permute(0, 3, 1, 2)  # [BN, 8, H, W], channels-last strides
         for layer in list(self.dtransform)[1:]:
             y = layer(y)
         return y

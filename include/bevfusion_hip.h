@@ -314,6 +314,11 @@ int bfhip_bev_nhwc_to_sparse(const void *grad_out, long long stride_b, long long
  *   counts (optional, f32[ncam,fH,fW,D], cleared by the caller) receives the depth-bin histogram of the hit
  *   pixels; bfhip_depth_histogram normalises it (bin 0 excluded, as :670-674) or rebuilds it from a depth image.
  * --------------------------------------------------------------------------------------- */
+/* Gradient of the first dtransform layer, Conv2d(1, 8, 1) on the one-channel depth image (BF/depth_lss.py:592-594; its
+ * autograd backward in the reference): y[m][c] = b[c] + d[m] * w[c] over the M = BN * iH * iW pixels.  dy bf16 [M][8] dense,
+ * d bf16 [M] -> out f32[16] = {db[0..8), dw[0..8)}; fp32 accumulation, fixed-order sums (deterministic). */
+size_t bfhip_depth_lift_bwd_workspace_bytes(void);
+int bfhip_depth_lift_bwd(const void *dy, const void *d, long long M, float *out, void *workspace, size_t workspace_bytes, void *stream);
 size_t bfhip_rasterise_depth_workspace_bytes(int ncam, int iH, int iW);
 int bfhip_rasterise_depth(const float *points, int n, int f, const float *inv_rot, const float *aug_trans,
                           const float *lidar2image, const float *img_aug, int ncam, int iH, int iW,

@@ -62,3 +62,34 @@ def test_duplicates_last_point_wins_and_empty(dev):
     assert np.array_equal(d.cpu().numpy()[0, :, 0], want) and (want > 0).sum() >= 1
     empty = vt.rasterise_depth(img, [torch.zeros(0, 5, device=dev)], t["lidar2image"], t["img_aug_matrix"], t["lidar_aug_matrix"])
     assert not empty.any()
+
+
+@pytest.mark.parametrize("shape", [(24, 256, 704), (3, 37, 53), (1, 1, 5)])
+def test_first_dtransform_layer_gradients(dev, shape):
+    """Conv2d(1, 8, 1) on the one-channel depth image (BF/depth_lss.py:592-594) as y = b + d * w in channels-last bf16, with
+    both parameter gradients from one pass over dy (csrc/raster.hip depth_lift_bwd_kernel): forward = the conv on the bf16-rounded
+    operands up to the final bf16 rounding; dw / db against the fp64 sums over the same bf16 values (<= 1e-5 rel: fp32 accumulation only, where
+    torch's own bf16 backward rounds the product tensor first); at the full batch-4 size (24 x 256 x 704) and on odd extents;
+    deterministic run to run."""
+    from bevfusion_amd.depth_lss import _DepthLift
+    BN, H, W = shape
+    g = torch.Generator(device="cpu").manual_seed(5)
+    d = (torch.rand(BN, H, W, 1, generator=g) * 60).to(dev)
+    d = torch.where(torch.rand(BN, H, W, 1, generator=g).to(dev) < 0.9, torch.zeros_like(d), d).to(torch.bfloat16)   # sparse depth image
+    w = torch.randn(8, 1, 1, 1, generator=g).to(dev).requires_grad_(True)
+    b = torch.randn(8, generator=g).to(dev).requires_grad_(True)
+    dy = torch.randn(BN, H, W, 8, generator=g).to(dev).to(torch.bfloat16)
+    y = _DepthLift.apply(d, w, b)
+    ref = torch.nn.functional.conv2d(d.permute(0, 3, 1, 2).float(), w.detach().to(torch.bfloat16).float(), b.detach().to(torch.bfloat16).float())
+    # one bf16 rounding of b + d * w either way (fused vs separate multiply-add in fp32 may flip a rounding: <= 1 ulp)
+    assert y.dtype == torch.bfloat16 and bool(((y.permute(0, 3, 1, 2).float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-30).all())
+    y.backward(dy)
+    dw64 = (dy.double() * d.double()).sum(dim=(0, 1, 2))
+    db64 = dy.double().sum(dim=(0, 1, 2))
+    assert w.grad.shape == w.shape and w.grad.dtype == torch.float32
+    assert float((w.grad.view(8).double() - dw64).norm() / dw64.norm().clamp_min(1e-30)) < 1e-5
+    assert float((b.grad.double() - db64).norm() / db64.norm()) < 1e-5
+    first = (w.grad.clone(), b.grad.clone())
+    w.grad = b.grad = None
+    _DepthLift.apply(d, w, b).backward(dy)
+    assert torch.equal(w.grad, first[0]) and torch.equal(b.grad, first[1])
