@@ -65,7 +65,7 @@ def wgrad_join():
 # hooks this path never reaches (grad_sync.FlatGradAllReduce, which runs after the pass, is fine).  Not used while a HIP graph is being captured (the table upload is host memory of this step) or
 # with the side-stream option above.
 WGRAD_GROUPED = os.environ.get("BFHIP_WGRAD_GROUPED", "1") == "1"
-_PENDING = []      # (x, dy, weight, row of the layer table, producing stream) of the running backward pass
+_PENDING = {}      # backward pass (graph task id) -> [(x, dy, weight, row of the layer table, producing stream)]
 _GROUPABLE = {}    # geometry -> bool
 _GROUP_STATE = {}  # device -> _WgradGroupState
 _LAYER_DT = None
@@ -122,24 +122,33 @@ def _defer_wgrad(x, dy, weight, stride, pad, dil):
     ldx, ldg = _nhwc_view(x), _nhwc_view(dy)
     if ldx is None or ldg is None:
         return False
-    if not _PENDING:
+    # one list per backward pass (graph task): a pass that died with an exception leaves its list behind without ever running
+    # its callback -- the next pass must neither inherit those records nor skip queuing its own callback; a re-entrant pass
+    # (checkpointing) has its own id and its own callback
+    tid = torch._C._current_graph_task_id()
+    pend = _PENDING.get(tid)
+    if pend is None:
+        if tid < 0:
+            return False  # not inside a backward pass of the engine
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-        except RuntimeError:  # not inside a backward pass of the engine
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_wgrads(tid))
+        except RuntimeError:
             return False
+        for old in [k for k in _PENDING if k < tid - 8]:
+            del _PENDING[old]
+        pend = _PENDING[tid] = []
     row = (x.data_ptr(), dy.data_ptr(), 0, ldx, ldg, N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
            1 if weight.dtype == torch.bfloat16 else 0, 0)
-    _PENDING.append((x, dy, weight, row, _lib.stream_of(x)))
+    pend.append((x, dy, weight, row, _lib.stream_of(x)))
     return True
 
 
-def _flush_wgrads():
-    """End of a backward pass: dW of every collected layer in one group per device; stores / accumulates weight.grad."""
+def _flush_wgrads(tid):
+    """End of backward pass `tid`: dW of every collected layer in one group per device; stores / accumulates weight.grad."""
     import ctypes
 
     import numpy as np
-    pend = _PENDING[:]
-    _PENDING.clear()
+    pend = _PENDING.pop(tid, None)
     if not pend:
         return
     by_dev = {}

@@ -328,6 +328,38 @@ def test_grouped_weight_gradients_match_the_in_line_launches(dev, monkeypatch, w
         assert torch.equal(b, c)                                         # fixed-order slab sums: bit-identical run to run
 
 
+def test_grouped_weight_gradients_survive_a_failed_backward_pass(dev):
+    """A backward pass that dies with an exception after a convolution has queued its weight gradient never runs its end-of-pass
+    callback; the next pass must start its own list and its own callback (records are kept per graph task), not inherit the dead
+    one's records or wait for a callback that will not come."""
+    from bevfusion_amd.conv2d import Conv2d
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t, fail):
+            ctx.fail = fail
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            if ctx.fail:
+                raise RuntimeError("boom")
+            return g, None
+
+    torch.manual_seed(0)
+    conv = Conv2d(32, 64, 3, padding=1, bias=False).to(dev).train()
+    conv.weight.data = conv.weight.data.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(3, 32, 48, 88, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    conv(Boom.apply(x, False)).float().square().mean().backward()
+    want = conv.weight.grad.clone()
+    conv.weight.grad = None
+    with pytest.raises(RuntimeError, match="boom"):
+        conv(Boom.apply(x, True)).float().square().mean().backward()
+    assert conv.weight.grad is None
+    conv(Boom.apply(x, False)).float().square().mean().backward()
+    assert torch.equal(conv.weight.grad, want)
+
+
 def test_grouped_weight_gradient_full_size_linearity(dev):
     """Size-independent property at the ConvFuser's real size (4 x 336 x 180 x 180 -> 256, 3x3): dW is linear in dy, so
     dW(dy1 + dy2) = dW(dy1) + dW(dy2) up to bf16 rounding of the operands -- checked on fp32 weights with dy values that are
