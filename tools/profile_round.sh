@@ -35,6 +35,7 @@ elif [ "$part" = B ]; then
   run timeout -k 10 200 python3 tools/wgrad_layers.py > $O/sparse_layers.json 2> $O/wgrad_layers.err || exit 1
 elif [ "$part" = D ]; then
   run timeout -k 10 280 python3 tools/wgrad2d_layers.py > $O/conv_wgrad_layers.txt 2> $O/wgrad2d.err || exit 1
+  run timeout -k 10 200 python3 tools/wgrad_group_micro.py > $O/conv_wgrad_group.json 2> $O/wgrad_group.err || exit 1
   run timeout -k 10 280 python3 tools/bn2d_layers.py > $O/bn2d_layers.txt 2> $O/bn2d.err || exit 1
   run timeout -k 10 200 python3 tools/lift_splat_variants.py > $O/lift_splat_variants.json 2> $O/ls.err || exit 1
   run bash tools/pmc_lift_splat.sh > $O/lift_splat_counters.txt 2>&1 || exit 1
