@@ -92,7 +92,7 @@ def build_torch_binding(force=False, verbose=True):
            "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=bfhip_torch_ext",
            "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
            "-L" + os.path.join(tdir, "lib"), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python",
-           "-L" + CSRC, "-lbevfusion_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tdir, "lib"), "-Wno-attributes"]
+           "-L" + CSRC, "-lbevfusion_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tdir, "lib"), "-Wno-attributes"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("torch binding failed to build:\n%s\n%s" % (r.stdout, r.stderr))

@@ -22,6 +22,28 @@ from torch import nn
 from . import _lib
 
 ENABLED = os.environ.get("BFHIP_CONV2D", "1") == "1"
+# C++ autograd front-end of the convolution Functions (csrc/torch_binding.cpp: conv2d, lib_conv2d, defer_wgrad): the same entry
+# points of the C ABI in the same order, without ~20-30 us of interpreter time per call and direction.  BFHIP_CONV_EXT=0 (or
+# conv2d.CONV_EXT = False, what tools that spy on the Python Functions set) keeps the Python classes below.
+CONV_EXT = os.environ.get("BFHIP_CONV_EXT", "1") == "1"
+
+
+def _conv_ext():
+    if not CONV_EXT or WGRAD_SIDE_STREAM:
+        return None
+    ext = _lib.torch_ext()
+    if ext is None or not hasattr(ext, "conv2d"):
+        return None
+    ext.set_wgrad_grouped(bool(WGRAD_GROUPED))
+    return ext
+
+
+def _cached_wt(weight):
+    """The transposed copy TransposedWeights keeps on a parameter, while the parameter has not changed since the refresh."""
+    cached = getattr(weight, "_bfhip_wt", None)
+    if cached is not None and cached[1] == weight._version and cached[2] == weight.data_ptr():
+        return cached[0]
+    return None
 MIN_PIXELS = int(os.environ.get("BFHIP_CONV2D_MIN_PIXELS", "2048"))  # tiny maps: the library's small-problem kernels win
 # layers with fewer input channels stay on the library: the one such layer of the model (dtransform 8 -> 32, 5x5 stride 4 on the
 # 256 x 704 depth images) has an 8-column data gradient over 4.3 M rows -- 0.30 ms on 64-column tiles; 33.43 vs 33.70 ms per step
@@ -122,6 +144,9 @@ def _defer_wgrad(x, dy, weight, stride, pad, dil):
     ldx, ldg = _nhwc_view(x), _nhwc_view(dy)
     if ldx is None or ldg is None:
         return False
+    ext = _conv_ext()
+    if ext is not None:  # one list per pass, whichever front-end a layer went through
+        return bool(ext.defer_wgrad(x, dy, weight, stride, pad, dil))
     # one list per backward pass (graph task): a pass that died with an exception leaves its list behind without ever running
     # its callback -- the next pass must neither inherit those records nor skip queuing its own callback; a re-entrant pass
     # (checkpointing) has its own id and its own callback
@@ -584,8 +609,23 @@ def _one(v):
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, emit_stats=False, dgrad_lib=False, fork=False):
     """y = conv2d(x, weight, bias) on the HIP path (bf16, channels-last); returns (y, stat_partial | None) and, with `fork`,
     a third output: x again, for a second consumer whose gradient the data gradient's epilogue adds (see _Conv2dFunction)."""
+    ext = _conv_ext() if x.is_cuda and x.dim() == 4 and not weight._backward_hooks else None
+    if ext is not None:
+        out = ext.conv2d(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats), bool(dgrad_lib), int(fork),
+                         None if dgrad_lib else _cached_wt(weight))
+        partial = out[1] if emit_stats else None
+        return (out[0], partial, out[2]) if fork else (out[0], partial)
     return _Conv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(emit_stats), bool(dgrad_lib),
                                  int(fork))
+
+
+def lib_conv2d(x, weight, stride, padding, dilation, dgrad_hip=False):
+    """Library forward (and data gradient unless `dgrad_hip`), weight gradient on csrc/conv2d.hip (_LibConvHipWgradFunction)."""
+    ext = _conv_ext() if x.is_cuda and x.dim() == 4 and not weight._backward_hooks else None
+    if ext is not None:
+        return ext.lib_conv2d(x, weight, int(stride), int(padding), int(dilation), bool(dgrad_hip),
+                              _cached_wt(weight) if dgrad_hip else None)
+    return _LibConvHipWgradFunction.apply(x, weight, stride, padding, dilation, dgrad_hip)
 
 
 class Conv2d(nn.Conv2d):
@@ -663,7 +703,7 @@ class Conv2dHipWgrad(Conv2d):
             if partial is not None:
                 y._bfhip_stat_partial = (partial, y.data_ptr(), y._version)
             return y
-        return _LibConvHipWgradFunction.apply(x, self.weight, s, p, d, self.dgrad == "hip")
+        return lib_conv2d(x, self.weight, s, p, d, self.dgrad == "hip")
 
     def forward_fork(self, x, subsample=1):
         """(conv(x), x'): x' is x for a second consumer (the identity branch of a residual block); when this layer runs forward and

@@ -287,13 +287,18 @@ def _wgrad_stack(dev, dtype):
     return convs, run
 
 
+@pytest.mark.parametrize("front", ["python", "ext"])
 @pytest.mark.parametrize("wdtype", [torch.bfloat16, torch.float32])
-def test_grouped_weight_gradients_match_the_in_line_launches(dev, monkeypatch, wdtype):
+def test_grouped_weight_gradients_match_the_in_line_launches(dev, monkeypatch, wdtype, front):
     """conv2d.WGRAD_GROUPED (csrc/conv2d.hip: conv_wgrad_group_kernel): dW of all layers of a backward pass in one launch per tile
     shape at the end of the pass equals the per-layer launches up to the fp32 summation order (the pixel range is cut into a
     different number of splits: <= 1e-5 rel on fp32 dW, one bf16 rounding on bf16 dW); the gradients are in place when
     backward() returns, a second pass without clearing .grad accumulates, and the result is deterministic."""
     from bevfusion_amd import conv2d as c2
+    # both front-ends of the convolution Functions: the Python classes of conv2d.py and csrc/torch_binding.cpp
+    monkeypatch.setattr(c2, "CONV_EXT", front == "ext")
+    if front == "ext" and (_lib.torch_ext() is None or not hasattr(_lib.torch_ext(), "conv2d")):
+        pytest.fail("bfhip_torch_ext.so is missing or stale: the C++ front-end must be built in-tree")
     convs, run = _wgrad_stack(dev, wdtype)
     x = torch.randn(3, 32, 48, 88, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     calls = []
@@ -316,7 +321,10 @@ def test_grouped_weight_gradients_match_the_in_line_launches(dev, monkeypatch, w
         res.setdefault(grouped, []).append((first, second, n_inline, n_group))
     (f0, s0, inline0, group0), = res[False]
     (f1, s1, inline1, group1), (f2, s2, _, _) = res[True]
-    assert (inline0, group0) == (7, 0) and (inline1, group1) == (1, 1)   # 7 HIP conv calls; only the 6 x 11 layer keeps its own launch
+    if front == "python":
+        assert (inline0, group0) == (7, 0) and (inline1, group1) == (1, 1)   # 7 HIP conv calls; only the 6 x 11 layer keeps its own launch
+    else:
+        assert inline0 + group0 + inline1 + group1 == 0 and _lib.torch_ext().pending_wgrads() == 0   # nothing went through ctypes
     assert not c2._PENDING
     tol = 1e-5 if wdtype == torch.float32 else 2.0 ** -7
     for a, b, a2, b2 in zip(f0, f1, s0, s1):
@@ -328,11 +336,14 @@ def test_grouped_weight_gradients_match_the_in_line_launches(dev, monkeypatch, w
         assert torch.equal(b, c)                                         # fixed-order slab sums: bit-identical run to run
 
 
-def test_grouped_weight_gradients_survive_a_failed_backward_pass(dev):
+@pytest.mark.parametrize("front", ["python", "ext"])
+def test_grouped_weight_gradients_survive_a_failed_backward_pass(dev, monkeypatch, front):
     """A backward pass that dies with an exception after a convolution has queued its weight gradient never runs its end-of-pass
     callback; the next pass must start its own list and its own callback (records are kept per graph task), not inherit the dead
     one's records or wait for a callback that will not come."""
+    from bevfusion_amd import conv2d as c2
     from bevfusion_amd.conv2d import Conv2d
+    monkeypatch.setattr(c2, "CONV_EXT", front == "ext")
 
     class Boom(torch.autograd.Function):
         @staticmethod

@@ -30,6 +30,7 @@ def spy2(ctx, x, w, s, p, d, *more):
 
 
 c2._Conv2dFunction.forward, c2._LibConvHipWgradFunction.forward = staticmethod(spy1), staticmethod(spy2)
+c2.CONV_EXT = False  # the spies sit on the Python Functions
 with torch.autocast("cuda", dtype=torch.bfloat16):
     wl.step_model(wl.inputs, None, wl.gts)
 c2._Conv2dFunction.forward, c2._LibConvHipWgradFunction.forward = staticmethod(o1), staticmethod(o2)
