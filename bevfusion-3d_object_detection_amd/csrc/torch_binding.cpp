@@ -217,8 +217,9 @@ struct GroupState {  // per device: two pinned table images (alternating: a copy
   int flip = 0;
 };
 std::mutex g_mu;
-std::map<int, std::vector<PendingWgrad>> g_pending;  // graph task id -> records
-std::map<int, GroupState> g_group;                   // device index -> state
+// (heap objects that are never destroyed: their tensors must not be released after the HIP runtime / torch's allocators at exit)
+std::map<int, std::vector<PendingWgrad>> &g_pending = *new std::map<int, std::vector<PendingWgrad>>();  // graph task id -> records
+std::map<int, GroupState> &g_group = *new std::map<int, GroupState>();                                  // device index -> state
 bool g_grouped = true;
 
 void flush_wgrads(int tid) {
