@@ -81,9 +81,11 @@ def wgrad_join():
 # engine runs when the pass ends (before `backward()` returns, on the caller's streams) and computes dW of all collected layers
 # with one launch per tile shape plus one slab-sum launch (csrc/conv2d.hip: conv_wgrad_group_kernel), then stores / accumulates
 # `weight.grad` itself -- what AccumulateGrad would have done.  Consequences: x and dy of every layer live until the end of the
-# pass (a few GB at batch 4 beside 288 GB of HBM); tensor hooks on a conv WEIGHT do not fire for this gradient; and
-# `torch.autograd.grad(..., weight)` finds no gradient for the weight (it raises "appears to not have been used") -- switch the
-# grouping off for such calls, and under torch's DistributedDataParallel, whose bucket all-reduce is driven by the AccumulateGrad
+# pass (a few GB at batch 4 beside 288 GB of HBM); a weight with tensor hooks keeps the per-layer launch; so does a pass with an
+# explicit input list (`torch.autograd.grad(..., inputs)`, `backward(inputs=...)`: the engine captures those gradients from the
+# graph and must not touch .grad) when the C++ front-end is in use -- the Python-only path (BFHIP_TORCH_EXT=0) cannot see that and
+# `torch.autograd.grad(..., weight)` then finds no gradient for the weight (it raises "appears to not have been used"): switch the
+# grouping off for such calls there.  Switch it off, too, under torch's DistributedDataParallel, whose bucket all-reduce is driven by the AccumulateGrad
 # hooks this path never reaches (grad_sync.FlatGradAllReduce, which runs after the pass, is fine).  Not used while a HIP graph is being captured (the table upload is host memory of this step) or
 # with the side-stream option above.
 WGRAD_GROUPED = os.environ.get("BFHIP_WGRAD_GROUPED", "1") == "1"

@@ -298,6 +298,10 @@ bool defer_wgrad(const Tensor &x, const Tensor &dy, const Tensor &weight, int64_
   if (cap != hipStreamCaptureStatusNone) return false;
   const int tid = torch::autograd::get_current_graph_task_id();
   if (tid < 0) return false;
+  // torch.autograd.grad(..., inputs) / backward(inputs=...): the engine captures the requested gradients from the graph and must
+  // not touch .grad -- the pass has a non-empty execution plan then; every layer launches its own weight gradient and returns it
+  const auto *plan = torch::autograd::get_current_graph_task_exec_info();
+  if (plan && !plan->empty()) return false;
   PendingWgrad e;
   e.x = x; e.dy = dy; e.weight = weight; e.stream = stream;
   e.row = bfhip_wgrad_layer{x.data_ptr(), dy.data_ptr(), nullptr, (int32_t)ldx, (int32_t)ldg, (int32_t)N, (int32_t)H, (int32_t)W,
