@@ -232,6 +232,8 @@ void flush_wgrads(int tid) {
     g_pending.erase(it);
   }
   if (pend.empty()) return;
+  static std::mutex flush_mu;  // the per-device buffers below are shared by all passes: one flush at a time
+  std::lock_guard<std::mutex> one_at_a_time(flush_mu);
   at::NoGradGuard no_grad;
   std::map<int, std::vector<size_t>> by_dev;
   for (size_t i = 0; i < pend.size(); ++i) by_dev[pend[i].x.get_device()].push_back(i);

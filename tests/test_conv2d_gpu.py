@@ -371,11 +371,13 @@ def test_grouped_weight_gradients_survive_a_failed_backward_pass(dev, monkeypatc
     assert torch.equal(conv.weight.grad, want)
 
 
-def test_autograd_grad_with_respect_to_a_weight_is_not_deferred(dev):
+def test_autograd_grad_with_respect_to_a_weight_is_not_deferred(dev, monkeypatch):
     """torch.autograd.grad(y, (x, weight)): the engine captures both gradients from the graph and leaves .grad alone, so the layer
     must launch its own weight gradient and return it (the C++ front-end sees the pass's explicit input list); the result equals
     what backward() stores through the grouped launch up to the split count."""
     from bevfusion_amd import conv2d as c2
+    monkeypatch.setattr(c2, "CONV_EXT", True)
+    monkeypatch.setattr(c2, "WGRAD_GROUPED", True)
     if c2._conv_ext() is None:
         pytest.fail("bfhip_torch_ext.so is missing or stale: the C++ front-end must be built in-tree")
     torch.manual_seed(0)
