@@ -943,7 +943,7 @@ __global__ __launch_bounds__(PG * PX * 256, 1) void conv_wgrad_wide_kernel(const
 // Launched one by one, each layer is cut into exactly one residency round (256 workgroups): 6-9 steps of 64 pixels per workgroup
 // on the ~50 small layers of the ResNet trunk, where the ring's prologue, the 128 KB slab store of every workgroup and the tail of
 // the launch cost more than the steps (28-45 us each at 170-310 TFLOP/s), and splits x dW fp32 slab bytes whatever the layer
-// (2.2 GB written per step).  In a group every workgroup runs ~`target_steps` steps of its layer (default 192): slab bytes fall
+// (2.2 GB written per step).  In a group every workgroup runs ~`target_steps` steps of its layer (default 96): slab bytes fall
 // with the split count, and there is one tail per step instead of one per layer.
 // XCD placement: hardware workgroup b runs on XCD b % 8.  The host cuts the group's workgroup list (layers in descending order
 // of steps per workgroup, each layer split-major) into 8 consecutive chunks of equal total STEPS; XCD c works through chunk c in
@@ -1694,15 +1694,16 @@ BFHIP_EXPORT int bfhip_conv2d_wgrad_groupable(int N, int H, int W, int Cin, int 
 
 // Plans the group and writes the image of its device table (header + one item per layer) into table_host; the caller copies
 // the image to the device (stream-ordered, before the launch) and provides *slab_bytes of workspace.  target_steps: 64-pixel
-// steps per workgroup to aim for (<= 0: BFHIP_WGRAD_GROUP_STEPS or 192: the 77 layers of the full step at 32 / 64 / 96 / 128 / 192 / 256 steps take 3.29 / 2.95 /
-// 2.80 / 2.80 / 2.83 / 2.84 ms with 1.9 / 1.0 / 0.73 / 0.58 / 0.44 / 0.36 GB of slabs).
+// steps per workgroup to aim for (<= 0: BFHIP_WGRAD_GROUP_STEPS or 96: the 77 layers of the full step at 32 / 64 / 96 / 128 / 192 / 256 steps take 3.29 / 2.95 /
+// 2.80 / 2.80 / 2.83 / 2.84 ms with 1.9 / 1.0 / 0.73 / 0.58 / 0.44 / 0.36 GB of slabs; inside the full step, ten alternating pairs: 96
+// steps 25.9 ms, 192 steps 26.3 ms (median) -- the last residency round of 192-step workgroups is a 260 us tail).
 BFHIP_EXPORT int bfhip_conv2d_wgrad_group_plan(const void *layers_, int n, int target_steps, void *table_host, size_t table_bytes,
                                                size_t *slab_bytes) {
   const WgradLayerDesc *L = (const WgradLayerDesc *)layers_;
   BFHIP_REQUIRE(L && n > 0 && table_host && slab_bytes, "conv2d_wgrad_group_plan: bad arguments");
   BFHIP_REQUIRE(table_bytes >= bfhip_conv2d_wgrad_group_table_bytes(n), "conv2d_wgrad_group_plan: table too small");
   if (target_steps <= 0) {
-    static const int env = [] { const char *e = getenv("BFHIP_WGRAD_GROUP_STEPS"); return e && atoi(e) > 0 ? atoi(e) : 192; }();
+    static const int env = [] { const char *e = getenv("BFHIP_WGRAD_GROUP_STEPS"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
     target_steps = env;
   }
   WgradGroupHeader hd;

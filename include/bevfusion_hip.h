@@ -537,7 +537,7 @@ int bfhip_conv2d_wgrad(const void *x, int ldx, const void *dy, int ldg, void *dw
  *   bfhip_conv2d_wgrad_groupable()       1 if the layer's geometry can join a group (else: bfhip_conv2d_wgrad)
  *   bfhip_conv2d_wgrad_group_table_bytes size of the table image for n layers
  *   bfhip_conv2d_wgrad_group_plan()      host only: plans splits / XCD chunks, writes the table image into table_host (host memory,
- *                                        e.g. pinned) and the slab workspace size into *slab_bytes; target_steps <= 0: default 192
+ *                                        e.g. pinned) and the slab workspace size into *slab_bytes; target_steps <= 0: default 96
  *   bfhip_conv2d_wgrad_group_launch()    table_dev = device copy of the image (copied by the caller, stream-ordered before this
  *                                        call); slab: 256-byte aligned device workspace of >= *slab_bytes */
 typedef struct bfhip_wgrad_layer {

@@ -131,7 +131,7 @@ def test_grouped_weight_gradient_plan_is_a_partition():
         n_items, n_shape, first, blocks, grid, rblocks = hd[0], hd[1:4], hd[4:7], hd[7:10], hd[10:13], hd[16]
         chunks = hd[18:45].reshape(3, 9)
         items = img[256:].view(item_dt)
-        assert n_items == n and n_shape[0] == 0 and n_shape[1] + n_shape[2] == n and hd[17] == (target or 192)
+        assert n_items == n and n_shape[0] == 0 and n_shape[1] + n_shape[2] == n and hd[17] == (target or 96)
         assert sorted(items["dw"].tolist()) == sorted(L["dw"].tolist())            # every layer exactly once
         end = 0
         for it in items:                                                          # table order = slab order
