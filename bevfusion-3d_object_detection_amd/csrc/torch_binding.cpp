@@ -2,9 +2,10 @@
 //
 // The C ABI (include/bevfusion_hip.h) stays the boundary; this file only replaces the ctypes + Python autograd.Function
 // plumbing for the ops that are called ~100 times per training step (fused BatchNorm over channels-last activations and
-// over sparse feature matrices): a Python custom Function costs ~50 us of host time per call (forward + backward, GIL
-// hand-over in the autograd engine), which made the step host-bound once the kernels themselves were fast.  Here a call
-// is: pybind -> torch::autograd::Function::apply -> at::empty -> bfhip_* (plain C call) on the current HIP stream.
+// over sparse feature matrices; the dense convolution Functions with the end-of-pass group of their weight gradients): a
+// Python custom Function costs ~50 us of host time per call (forward + backward, GIL hand-over in the autograd engine),
+// which made the step host-bound once the kernels themselves were fast.  Here a call is: pybind ->
+// torch::autograd::Function::apply -> at::empty -> bfhip_* (plain C call) on the current HIP stream.
 // Host-only C++ (no kernels); built by _build.py against the installed torch and linked to libbevfusion_hip.so.
 #include <torch/extension.h>
 #include <torch/csrc/autograd/engine.h>
