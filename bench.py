@@ -56,6 +56,10 @@ DENSE_OPS = ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "bn2d_fwd", "bn2d_bwd
 # `kernel_ms_per_step`: the same ops timed over ISOLATED_STEPS extra steps after the timed region with the side streams off
 # (one queue, nothing beside them) -- the number a rocprofv3 kernel trace reproduces.
 HOST_SLEEP_US = int(os.environ.get("BENCH_HOST_SLEEP_US", "0"))
+# The backward pass runs on the calling thread (BENCH_AUTOGRAD_MT=1: on the autograd engine's device thread, torch's default): with one
+# process per GPU there is nothing for a per-device thread to overlap, and the hand-over costs host time -- issue time of the `full`
+# step 24.4-24.6 -> 20.1-21.0 ms on a moderately busy host (tools/host_bound.py, alternating runs); same kernels, same streams.
+AUTOGRAD_ON_CALLER = os.environ.get("BENCH_AUTOGRAD_MT", "0") == "0"
 PREWARM_STEPS = int(os.environ.get("BENCH_PREWARM_STEPS", "6"))
 SETTLE_MAX_S = float(os.environ.get("BENCH_SETTLE_MAX_S", "15"))
 
@@ -260,6 +264,8 @@ class _ModelWorkload:
             # themselves at the end of the pass and never reach those hooks
             _c2.WGRAD_GROUPED = False
         self.wgrad_grouped = bool(_c2.WGRAD_GROUPED and not _c2.WGRAD_SIDE_STREAM and not self.use_graph)
+        self.backward_on_caller = bool(AUTOGRAD_ON_CALLER and not (ddp and GRAD_SYNC == "ddp"))
+        torch.autograd.set_multithreading_enabled(not self.backward_on_caller)
         self._wgrad_join = _c2.wgrad_join if _c2.WGRAD_SIDE_STREAM else None
         self._params = [p for p in self.model.parameters() if p.requires_grad]
         # ground truth as a dataloader hands it over: per-frame host tensors (boxes [G, 9], labels [G]), G ~ U(15, 60)
@@ -921,6 +927,7 @@ def main():
         if hasattr(wl, "n_params"):
             line["config"]["dense_weight_gradients"] = ("one grouped launch per tile shape at the end of the backward pass"
                                                         if getattr(wl, "wgrad_grouped", False) else "one launch pair per layer")
+            line["config"]["backward_pass_thread"] = "caller" if getattr(wl, "backward_on_caller", False) else "autograd engine device thread"
             line["config"]["trainable_params"] = wl.n_params
         if torch.is_tensor(first_loss) and torch.is_tensor(last_loss):
             # the optimizer really steps: total loss of the (fixed) batch at the first warm-up step and at the last timed step

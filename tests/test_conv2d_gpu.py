@@ -371,6 +371,41 @@ def test_grouped_weight_gradients_survive_a_failed_backward_pass(dev, monkeypatc
     assert torch.equal(conv.weight.grad, want)
 
 
+def test_backward_on_the_calling_thread_gives_the_same_gradients(dev):
+    """bench.py runs the backward pass on the calling thread (`torch.autograd.set_multithreading_enabled(False)`: one process per
+    GPU needs no per-device engine thread, and the hand-over costs 3-4 ms of host time per step).  The grouped weight gradients hang
+    on an engine callback and one branch of this network runs on a second HIP stream: both must behave the same either way --
+    bit-identical gradients (these kernels are deterministic)."""
+    convs, run = _wgrad_stack(dev, torch.bfloat16)
+    side = torch.cuda.Stream(device=dev)
+    x = torch.randn(3, 32, 48, 88, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def step():
+        for p in convs.parameters():
+            p.grad = None
+        main = torch.cuda.current_stream(dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            a = run(x)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):      # a second branch through the first two layers, on its own stream
+                b = convs[1](convs[0](x * 0.5))
+            main.wait_stream(side)
+            b.record_stream(main)
+            (a.float().square().mean() + b.float().square().mean()).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in convs.parameters()]
+
+    want = step()
+    try:
+        torch.autograd.set_multithreading_enabled(False)
+        got = step()
+    finally:
+        torch.autograd.set_multithreading_enabled(True)
+    assert all(torch.isfinite(g.float()).all() and g.float().abs().sum() > 0 for g in got)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+
+
 def test_autograd_grad_with_respect_to_a_weight_is_not_deferred(dev, monkeypatch):
     """torch.autograd.grad(y, (x, weight)): the engine captures both gradients from the graph and leaves .grad alone, so the layer
     must launch its own weight gradient and return it (the C++ front-end sees the pass's explicit input list); the result equals
